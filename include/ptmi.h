@@ -1,0 +1,136 @@
+/*
+ * ptmi.h -- C ABI of the MI355X-native path-tracing backend (libptmi.so).
+ *
+ * This is the drop-in boundary for the hot path of 0Xero7/pathtrace: the seam between the
+ * reference's tile scheduler (main.go:832-899, tile.go, renderer.go) and its integrator /
+ * BVH traversal (tracer.go, linear_bvh.go, utils.go).  Each entry point cites the reference
+ * interface it replaces.  INTEGRATION.md shows the cgo shim a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all entry points return 0 on success and a negative
+ *     PTMI_ERR_* code on failure; the text of the last error is ptmi_last_error(ctx)
+ *     (ctx may be NULL for errors raised before a context exists).  Nothing aborts or throws
+ *     across this boundary (the reference panics instead: skybox.go:55-62, obj_loader.go:35-45).
+ *   - caller-owned buffers are only borrowed for the duration of a call;
+ *     "upload"/"build" calls copy what they need into GPU memory owned by the context.
+ *   - one ptmi_ctx per GPU; calls on one ctx must be serialised by the caller; different
+ *     contexts may be driven from different OS threads.  Every entry point selects the
+ *     context's device itself (hipSetDevice), so Go's goroutine->thread migration is harmless.
+ *   - entry points ending in _dev take DEVICE pointers on the context's GPU and enqueue on
+ *     `stream` (a hipStream_t passed as void*, NULL = default stream) without synchronising.
+ *   - vectors are packed xyz float32 triples (the reference's Vec3, vec3.go:9-11).
+ */
+#ifndef PTMI_H
+#define PTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ptmi_ctx ptmi_ctx;
+
+enum {
+    PTMI_OK = 0,
+    PTMI_ERR_INVALID = -1,     /* bad argument (null pointer, index out of range, ...)        */
+    PTMI_ERR_NO_DEVICE = -2,   /* no usable GPU / HIP runtime failure at create               */
+    PTMI_ERR_HIP = -3,         /* a HIP call failed; text in ptmi_last_error                   */
+    PTMI_ERR_NO_BVH = -4,      /* query before ptmi_build_bvh / ptmi_upload_bvh               */
+    PTMI_ERR_DEPTH = -5,       /* tree deeper than the traversal stack (reference: 64 entries) */
+    PTMI_ERR_NO_SCENE = -6,    /* ptmi_render before ptmi_upload_scene                         */
+    PTMI_ERR_OOM = -7
+};
+
+/* ------------------------------------------------------------------ context */
+
+/* No reference counterpart (the reference is one process with shared memory); creates the
+ * per-GPU state that stands in for the globals of main.go. */
+int ptmi_create(int device, ptmi_ctx **out);
+void ptmi_destroy(ptmi_ctx *ctx);
+const char *ptmi_last_error(const ptmi_ctx *ctx);
+const char *ptmi_version(void);
+
+/* ------------------------------------------------------------------ BVH */
+
+/* Replaces BuildBVH (bvh.go:248-275) + ConstructLinearBVH (linear_bvh.go:108-112) as called at
+ * main.go:804-810.  verts_xyz: nverts*3 floats; tri_idx: ntris*3 vertex indices (the reference's
+ * `tris []int`); bounds = {x1,x2,y1,y2,z1,z2} root box (the reference passes +-1000);
+ * threshold / depth as bvh.go:148 (reference: 4, 42).  The tree produced is bit-identical in
+ * topology, bounds and leaf order to the reference's, then packed for the GPU and uploaded. */
+int ptmi_build_bvh(ptmi_ctx *ctx, const float *verts_xyz, uint64_t nverts, const uint32_t *tri_idx,
+                   uint64_t ntris, const float bounds[6], int threshold, int depth);
+
+/* Host-only form of the builder: the same code ptmi_build_bvh runs, without touching a GPU
+ * (start-up work in the reference too: main.go:803-810 runs before any worker starts).  The
+ * handle keeps copies of the vertex / index arrays; ptmi_upload_host_bvh packs and uploads it. */
+typedef struct ptmi_host_bvh ptmi_host_bvh;
+int ptmi_host_bvh_build(const float *verts_xyz, uint64_t nverts, const uint32_t *tri_idx, uint64_t ntris,
+                        const float bounds[6], int threshold, int depth, ptmi_host_bvh **out);
+void ptmi_host_bvh_free(ptmi_host_bvh *bvh);
+int ptmi_host_bvh_sizes(const ptmi_host_bvh *bvh, uint64_t *n_nodes, uint64_t *n_tri_ids);
+int ptmi_host_bvh_get(const ptmi_host_bvh *bvh, float *node_bounds, uint8_t *is_leaf, uint32_t *tri_offset,
+                      uint32_t *tri_count, uint32_t *second_child, uint32_t *tri_ids);
+
+/* Upload a tree that is already in the reference's LinearBVH form (linear_bvh.go:11-21,72-75):
+ * node_bounds = 6 floats per node (min xyz, max xyz); tri_ids = the Triangles slice as triangle
+ * numbers (tri.Index/3).  Replaces nothing in the reference; lets a Go host keep its own builder. */
+int ptmi_upload_bvh(ptmi_ctx *ctx, const float *verts_xyz, uint64_t nverts, const uint32_t *tri_idx,
+                    uint64_t ntris, uint64_t n_nodes, const float *node_bounds, const uint8_t *is_leaf,
+                    const uint32_t *tri_offset, const uint32_t *tri_count, const uint32_t *second_child,
+                    uint64_t n_tri_ids, const uint32_t *tri_ids);
+
+/* Read the tree back in the reference's LinearBVH form (sizes first, then the arrays). */
+int ptmi_bvh_sizes(ptmi_ctx *ctx, uint64_t *n_nodes, uint64_t *n_tri_ids);
+int ptmi_get_linear_bvh(ptmi_ctx *ctx, float *node_bounds, uint8_t *is_leaf, uint32_t *tri_offset,
+                        uint32_t *tri_count, uint32_t *second_child, uint32_t *tri_ids);
+
+/* Replaces Box.GetStats(1) (bvh.go:109-146) as printed at main.go:809.  total_nodes follows the
+ * reference (it counts leaves); linear_nodes is len(LinearBVH.Nodes). */
+typedef struct {
+    int64_t max_depth, max_tris, min_tris, total_leafs, total_nodes, total_triangles;
+    int64_t linear_nodes, packed_inner_nodes;
+    double build_ms;
+} PtBvhStats;
+int ptmi_bvh_stats(ptmi_ctx *ctx, PtBvhStats *out);
+int ptmi_host_bvh_stats(const ptmi_host_bvh *bvh, PtBvhStats *out);
+int ptmi_upload_host_bvh(ptmi_ctx *ctx, const ptmi_host_bvh *bvh);
+
+/* ------------------------------------------------------------------ ray queries */
+
+/* Replaces (*LinearBVH).CheckIntersection (linear_bvh.go:116-170) for a batch of n rays.
+ * o_xyz, d_xyz: n*3 floats; tmax: n floats (the reference's stepSize); outputs prim_id[n] =
+ * tri.Index/3 of the hit triangle or -1, t[n] = best_t or 0 on a miss (reference returns
+ * (false, 0, nil)).  Host buffers; synchronous. */
+int ptmi_closest_hit(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n,
+                     int32_t *prim_id, float *t);
+/* Same, device buffers, asynchronous on `stream`. */
+int ptmi_closest_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax,
+                         uint64_t n, int32_t *prim_id, float *t, void *stream);
+
+/* Replaces (*LinearBVH).QuickCheckIntersection (linear_bvh.go:202-250): occluded[n] = 1 if any
+ * triangle is hit in (1e-5, tmax). */
+int ptmi_any_hit(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n,
+                 uint8_t *occluded);
+int ptmi_any_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n,
+                     uint8_t *occluded, void *stream);
+
+/* Work counters.  The reference only counts diffuse shading events (raysTraced, tracer.go:12,666);
+ * the traversal counters here define the algorithmic bytes of the roofline.
+ * Counting is off by default (it selects instrumented kernel variants). */
+typedef struct {
+    uint64_t closest_queries, any_queries;
+    uint64_t inner_visits;     /* inner nodes popped  (64 B each)  */
+    uint64_t tri_tests;        /* triangles tested    (48 B each)  */
+    uint64_t leaf_visits;
+    uint64_t diffuse_events;   /* == raysTraced (tracer.go:666)    */
+    uint64_t samples;          /* primary samples completed        */
+} PtCounters;
+int ptmi_set_counting(ptmi_ctx *ctx, int enabled);
+int ptmi_reset_counters(ptmi_ctx *ctx);
+int ptmi_counters(ptmi_ctx *ctx, PtCounters *out);   /* synchronises the device */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI_H */

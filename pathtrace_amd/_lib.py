@@ -1,0 +1,105 @@
+"""ctypes binding of libptmi.so (the C ABI declared in include/ptmi.h).
+
+The product path has no CPU fallback: if the HIP library is missing this module raises, and
+every query needs a GPU context.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptmi.so")
+
+PTMI_OK = 0
+ERR_NAMES = {-1: "PTMI_ERR_INVALID", -2: "PTMI_ERR_NO_DEVICE", -3: "PTMI_ERR_HIP", -4: "PTMI_ERR_NO_BVH",
+             -5: "PTMI_ERR_DEPTH", -6: "PTMI_ERR_NO_SCENE", -7: "PTMI_ERR_OOM"}
+
+
+class PtmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class PtBvhStats(C.Structure):
+    _fields_ = [("max_depth", C.c_int64), ("max_tris", C.c_int64), ("min_tris", C.c_int64),
+                ("total_leafs", C.c_int64), ("total_nodes", C.c_int64), ("total_triangles", C.c_int64),
+                ("linear_nodes", C.c_int64), ("packed_inner_nodes", C.c_int64), ("build_ms", C.c_double)]
+
+
+class PtCounters(C.Structure):
+    _fields_ = [("closest_queries", C.c_uint64), ("any_queries", C.c_uint64), ("inner_visits", C.c_uint64),
+                ("tri_tests", C.c_uint64), ("leaf_visits", C.c_uint64), ("diffuse_events", C.c_uint64),
+                ("samples", C.c_uint64)]
+
+
+class PtCamera(C.Structure):
+    """camera.go:9-15"""
+    _fields_ = [("position", C.c_float * 3), ("forward", C.c_float * 3), ("right", C.c_float * 3),
+                ("up", C.c_float * 3), ("frustum_distance", C.c_float)]
+
+
+class PtParams(C.Structure):
+    """The literals of main.go:441-452 that TraceRay receives positionally (main.go:875)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bounces", C.c_int32), ("scatter_rays", C.c_int32),
+                ("max_steps", C.c_int32), ("ambient", C.c_float), ("step_size", C.c_float), ("seed", C.c_uint32)]
+
+
+_P = C.c_void_p
+_F = C.POINTER(C.c_float)
+_U32 = C.POINTER(C.c_uint32)
+_U8 = C.POINTER(C.c_uint8)
+_I32 = C.POINTER(C.c_int32)
+_U64 = C.c_uint64
+
+# name -> (restype, argtypes).  tests/test_abi.py checks that this table and include/ptmi.h agree.
+SIGNATURES = {
+    "ptmi_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "ptmi_destroy": (None, [_P]),
+    "ptmi_last_error": (C.c_char_p, [_P]),
+    "ptmi_version": (C.c_char_p, []),
+    "ptmi_build_bvh": (C.c_int, [_P, _F, _U64, _U32, _U64, _F, C.c_int, C.c_int]),
+    "ptmi_host_bvh_build": (C.c_int, [_F, _U64, _U32, _U64, _F, C.c_int, C.c_int, C.POINTER(_P)]),
+    "ptmi_host_bvh_free": (None, [_P]),
+    "ptmi_host_bvh_sizes": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(_U64)]),
+    "ptmi_host_bvh_get": (C.c_int, [_P, _F, _U8, _U32, _U32, _U32, _U32]),
+    "ptmi_host_bvh_stats": (C.c_int, [_P, C.POINTER(PtBvhStats)]),
+    "ptmi_upload_host_bvh": (C.c_int, [_P, _P]),
+    "ptmi_upload_bvh": (C.c_int, [_P, _F, _U64, _U32, _U64, _U64, _F, _U8, _U32, _U32, _U32, _U64, _U32]),
+    "ptmi_bvh_sizes": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(_U64)]),
+    "ptmi_get_linear_bvh": (C.c_int, [_P, _F, _U8, _U32, _U32, _U32, _U32]),
+    "ptmi_bvh_stats": (C.c_int, [_P, C.POINTER(PtBvhStats)]),
+    "ptmi_closest_hit": (C.c_int, [_P, _F, _F, _F, _U64, _I32, _F]),
+    "ptmi_closest_hit_dev": (C.c_int, [_P, _P, _P, _P, _U64, _P, _P, _P]),
+    "ptmi_any_hit": (C.c_int, [_P, _F, _F, _F, _U64, _U8]),
+    "ptmi_any_hit_dev": (C.c_int, [_P, _P, _P, _P, _U64, _P, _P]),
+    "ptmi_set_counting": (C.c_int, [_P, C.c_int]),
+    "ptmi_reset_counters": (C.c_int, [_P]),
+    "ptmi_counters": (C.c_int, [_P, C.POINTER(PtCounters)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libptmi.so; raises (loudly) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C pathtrace_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None):
+    if rc != PTMI_OK:
+        msg = load().ptmi_last_error(ctx)
+        raise PtmiError(rc, msg.decode() if msg else "")

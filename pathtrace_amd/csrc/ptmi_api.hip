@@ -1,0 +1,452 @@
+// ptmi_api.hip -- C ABI (include/ptmi.h): context, BVH build/upload, batched ray queries.
+//
+// Kernels here: `extend` (closest hit, replaces LinearBVH.CheckIntersection, linear_bvh.go:116)
+// and `connect` (any hit, replaces QuickCheckIntersection, linear_bvh.go:202) over caller-provided
+// ray arrays.  One ray per lane, one wave per workgroup (a finished wave frees its slot without
+// waiting for neighbours), traversal stack in LDS.
+#include <chrono>
+#include <cstring>
+
+#include "ptmi_ctx.hpp"
+
+using namespace ptmi;
+
+static thread_local std::string g_last_error;
+
+namespace ptmi {
+int set_err(ptmi_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    g_last_error = msg;
+    return code;
+}
+int hip_err(ptmi_ctx *ctx, hipError_t e, const char *what) {
+    return set_err(ctx, PTMI_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+int ensure_stage(ptmi_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->stage_bytes) return PTMI_OK;
+    if (ctx->d_stage) { (void)hipFree(ctx->d_stage); ctx->d_stage = nullptr; ctx->stage_bytes = 0; }
+    size_t want = bytes + bytes / 4 + 4096;
+    PTMI_HIP(ctx, hipMalloc(&ctx->d_stage, want));
+    ctx->stage_bytes = want;
+    return PTMI_OK;
+}
+}  // namespace ptmi
+
+// ------------------------------------------------------------------------------------ kernels
+
+constexpr int WAVE = 64;
+
+template <bool COUNT>
+__device__ __forceinline__ void flush_counters(const TravCounters &c, unsigned long long *counters, int which_query,
+                                               uint32_t active) {
+    if (!COUNT) return;
+    uint32_t vi = c.inner, vt = c.tri, vl = c.leaf, va = active;
+    for (int off = 32; off > 0; off >>= 1) {
+        vi += __shfl_xor(vi, off); vt += __shfl_xor(vt, off); vl += __shfl_xor(vl, off); va += __shfl_xor(va, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counters[CNT_INNER], (unsigned long long)vi);
+        atomicAdd(&counters[CNT_TRI], (unsigned long long)vt);
+        atomicAdd(&counters[CNT_LEAF], (unsigned long long)vl);
+        atomicAdd(&counters[which_query], (unsigned long long)va);
+    }
+}
+
+template <int STACK, bool COUNT>
+__global__ __launch_bounds__(WAVE) void extend_kernel(DevBVH bvh, const float *__restrict__ o,
+                                                      const float *__restrict__ d, const float *__restrict__ tmax,
+                                                      uint64_t n, int32_t *__restrict__ prim, float *__restrict__ t,
+                                                      unsigned long long *counters) {
+    __shared__ uint32_t smem[STACK * WAVE];
+    const uint64_t r = (uint64_t)blockIdx.x * WAVE + threadIdx.x;
+    TravCounters cnt;
+    const bool live = r < n;
+    if (live) {
+        const float ox = o[3 * r], oy = o[3 * r + 1], oz = o[3 * r + 2];
+        const float dx = d[3 * r], dy = d[3 * r + 1], dz = d[3 * r + 2];
+        int p; float tt;
+        closest_hit<WAVE, COUNT>(bvh, smem + threadIdx.x, ox, oy, oz, dx, dy, dz, tmax[r], p, tt, cnt);
+        prim[r] = p; t[r] = tt;
+    }
+    flush_counters<COUNT>(cnt, counters, CNT_CLOSEST, live ? 1u : 0u);
+}
+
+template <int STACK, bool COUNT>
+__global__ __launch_bounds__(WAVE) void connect_kernel(DevBVH bvh, const float *__restrict__ o,
+                                                       const float *__restrict__ d, const float *__restrict__ tmax,
+                                                       uint64_t n, uint8_t *__restrict__ occluded,
+                                                       unsigned long long *counters) {
+    __shared__ uint32_t smem[STACK * WAVE];
+    const uint64_t r = (uint64_t)blockIdx.x * WAVE + threadIdx.x;
+    TravCounters cnt;
+    const bool live = r < n;
+    if (live) {
+        const float ox = o[3 * r], oy = o[3 * r + 1], oz = o[3 * r + 2];
+        const float dx = d[3 * r], dy = d[3 * r + 1], dz = d[3 * r + 2];
+        occluded[r] = any_hit<WAVE, COUNT>(bvh, smem + threadIdx.x, ox, oy, oz, dx, dy, dz, tmax[r], cnt) ? 1 : 0;
+    }
+    flush_counters<COUNT>(cnt, counters, CNT_ANY, live ? 1u : 0u);
+}
+
+template <int STACK>
+static void launch_extend(ptmi_ctx *ctx, const float *o, const float *d, const float *tmax, uint64_t n, int32_t *prim,
+                          float *t, hipStream_t s) {
+    dim3 grid((unsigned)((n + WAVE - 1) / WAVE)), block(WAVE);
+    if (ctx->counting)
+        hipLaunchKernelGGL((extend_kernel<STACK, true>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t,
+                           ctx->d_counters);
+    else
+        hipLaunchKernelGGL((extend_kernel<STACK, false>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t,
+                           ctx->d_counters);
+}
+template <int STACK>
+static void launch_connect(ptmi_ctx *ctx, const float *o, const float *d, const float *tmax, uint64_t n, uint8_t *occ,
+                           hipStream_t s) {
+    dim3 grid((unsigned)((n + WAVE - 1) / WAVE)), block(WAVE);
+    if (ctx->counting)
+        hipLaunchKernelGGL((connect_kernel<STACK, true>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
+                           ctx->d_counters);
+    else
+        hipLaunchKernelGGL((connect_kernel<STACK, false>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
+                           ctx->d_counters);
+}
+
+// ------------------------------------------------------------------------------------ context
+
+extern "C" const char *ptmi_version(void) { return "ptmi 0.1 (gfx950)"; }
+
+extern "C" const char *ptmi_last_error(const ptmi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+extern "C" int ptmi_create(int device, ptmi_ctx **out) {
+    if (!out) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_create: out is null");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return set_err(nullptr, PTMI_ERR_NO_DEVICE,
+                       std::string("ptmi_create: no HIP device (") + hipGetErrorString(e) + ")");
+    if (device < 0 || device >= ndev) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_create: device index out of range");
+    ptmi_ctx *ctx = new (std::nothrow) ptmi_ctx();
+    if (!ctx) return set_err(nullptr, PTMI_ERR_OOM, "ptmi_create: out of host memory");
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
+        (e = hipMalloc((void **)&ctx->d_counters, CNT_WORDS * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(ctx->d_counters, 0, CNT_WORDS * sizeof(unsigned long long))) != hipSuccess) {
+        set_err(nullptr, PTMI_ERR_HIP, std::string("ptmi_create: ") + hipGetErrorString(e));
+        delete ctx;
+        return PTMI_ERR_HIP;
+    }
+    *out = ctx;
+    return PTMI_OK;
+}
+
+static void free_bvh_device(ptmi_ctx *ctx) {
+    if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
+    if (ctx->d_tris) (void)hipFree(ctx->d_tris);
+    ctx->d_nodes = ctx->d_tris = nullptr;
+    ctx->have_bvh = false;
+}
+
+namespace ptmi { void free_scene(ptmi_ctx *ctx); }
+
+extern "C" void ptmi_destroy(ptmi_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_bvh_device(ctx);
+    ptmi::free_scene(ctx);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+// ------------------------------------------------------------------------------------ BVH
+
+static int upload_packed(ptmi_ctx *ctx, const float *verts, uint64_t nverts, const uint32_t *tri_idx, uint64_t ntris) {
+    const char *msg = "";
+    PackedBVH packed;
+    int rc = pack_bvh(ctx->lin, verts, tri_idx, packed, &msg);
+    if (rc) return set_err(ctx, rc, std::string("pack_bvh: ") + msg);
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    free_bvh_device(ctx);
+    size_t nb = packed.nodes.size() * sizeof(PackedNode), tb = packed.tris.size() * sizeof(PackedTri);
+    PTMI_HIP(ctx, hipMalloc((void **)&ctx->d_nodes, nb ? nb : 64));
+    PTMI_HIP(ctx, hipMalloc((void **)&ctx->d_tris, tb ? tb : 48));
+    if (nb) PTMI_HIP(ctx, hipMemcpy(ctx->d_nodes, packed.nodes.data(), nb, hipMemcpyHostToDevice));
+    if (tb) PTMI_HIP(ctx, hipMemcpy(ctx->d_tris, packed.tris.data(), tb, hipMemcpyHostToDevice));
+    ctx->root_ref = packed.root_ref;
+    ctx->max_depth = packed.max_depth;
+    ctx->packed_inner = packed.nodes.size();
+    ctx->packed_tris = packed.tris.size();
+    ctx->stats = linear_bvh_stats(ctx->lin);
+    ctx->verts.assign(verts, verts + 3 * nverts);
+    ctx->tri_idx.assign(tri_idx, tri_idx + 3 * ntris);
+    ctx->have_bvh = true;
+    return PTMI_OK;
+}
+
+struct ptmi_host_bvh {
+    LinearBVH lin;
+    std::vector<float> verts;
+    std::vector<uint32_t> tri_idx;
+    double build_ms = 0.0;
+};
+
+extern "C" int ptmi_host_bvh_build(const float *verts_xyz, uint64_t nverts, const uint32_t *tri_idx, uint64_t ntris,
+                                   const float bounds[6], int threshold, int depth, ptmi_host_bvh **out) {
+    if (!out) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_host_bvh_build: out is null");
+    *out = nullptr;
+    ptmi_host_bvh *h = new (std::nothrow) ptmi_host_bvh();
+    if (!h) return set_err(nullptr, PTMI_ERR_OOM, "ptmi_host_bvh_build: out of host memory");
+    const char *msg = "";
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = build_linear_bvh(verts_xyz, nverts, tri_idx, ntris, bounds, threshold, depth, h->lin, &msg);
+    if (rc) {
+        delete h;
+        return set_err(nullptr, rc == -5 ? PTMI_ERR_DEPTH : PTMI_ERR_INVALID, std::string("ptmi_host_bvh_build: ") + msg);
+    }
+    h->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    h->verts.assign(verts_xyz, verts_xyz + 3 * nverts);
+    h->tri_idx.assign(tri_idx, tri_idx + 3 * ntris);
+    *out = h;
+    return PTMI_OK;
+}
+
+extern "C" void ptmi_host_bvh_free(ptmi_host_bvh *bvh) { delete bvh; }
+
+extern "C" int ptmi_host_bvh_sizes(const ptmi_host_bvh *bvh, uint64_t *n_nodes, uint64_t *n_tri_ids) {
+    if (!bvh || !n_nodes || !n_tri_ids) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_host_bvh_sizes: null argument");
+    *n_nodes = bvh->lin.nodes.size();
+    *n_tri_ids = bvh->lin.tri_ids.size();
+    return PTMI_OK;
+}
+
+static void export_linear(const LinearBVH &lin, float *node_bounds, uint8_t *is_leaf, uint32_t *tri_offset,
+                          uint32_t *tri_count, uint32_t *second_child, uint32_t *tri_ids) {
+    for (size_t i = 0; i < lin.nodes.size(); ++i) {
+        const LinNode &n = lin.nodes[i];
+        for (int a = 0; a < 3; ++a) { node_bounds[6 * i + a] = n.minb[a]; node_bounds[6 * i + 3 + a] = n.maxb[a]; }
+        is_leaf[i] = n.is_leaf; tri_offset[i] = n.tri_offset; tri_count[i] = n.tri_count; second_child[i] = n.second_child;
+    }
+    if (!lin.tri_ids.empty()) std::memcpy(tri_ids, lin.tri_ids.data(), lin.tri_ids.size() * sizeof(uint32_t));
+}
+
+extern "C" int ptmi_host_bvh_get(const ptmi_host_bvh *bvh, float *node_bounds, uint8_t *is_leaf, uint32_t *tri_offset,
+                                 uint32_t *tri_count, uint32_t *second_child, uint32_t *tri_ids) {
+    if (!bvh || !node_bounds || !is_leaf || !tri_offset || !tri_count || !second_child || !tri_ids)
+        return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_host_bvh_get: null argument");
+    export_linear(bvh->lin, node_bounds, is_leaf, tri_offset, tri_count, second_child, tri_ids);
+    return PTMI_OK;
+}
+
+static void fill_stats(const LinearBVH &lin, double build_ms, uint64_t packed_inner, PtBvhStats *out) {
+    BvhStats s = linear_bvh_stats(lin);
+    out->max_depth = s.max_depth; out->max_tris = s.max_tris; out->min_tris = s.min_tris;
+    out->total_leafs = s.total_leafs; out->total_nodes = s.total_nodes; out->total_triangles = s.total_triangles;
+    out->linear_nodes = (int64_t)lin.nodes.size();
+    out->packed_inner_nodes = (int64_t)packed_inner;
+    out->build_ms = build_ms;
+}
+
+extern "C" int ptmi_host_bvh_stats(const ptmi_host_bvh *bvh, PtBvhStats *out) {
+    if (!bvh || !out) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_host_bvh_stats: null argument");
+    uint64_t inner = 0;
+    for (const LinNode &n : bvh->lin.nodes) inner += n.is_leaf ? 0 : 1;
+    fill_stats(bvh->lin, bvh->build_ms, inner, out);
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_upload_host_bvh(ptmi_ctx *ctx, const ptmi_host_bvh *bvh) {
+    if (!ctx || !bvh) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_host_bvh: null argument");
+    ctx->lin = bvh->lin;
+    ctx->build_ms = bvh->build_ms;
+    return upload_packed(ctx, bvh->verts.data(), bvh->verts.size() / 3, bvh->tri_idx.data(), bvh->tri_idx.size() / 3);
+}
+
+extern "C" int ptmi_build_bvh(ptmi_ctx *ctx, const float *verts_xyz, uint64_t nverts, const uint32_t *tri_idx,
+                              uint64_t ntris, const float bounds[6], int threshold, int depth) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_build_bvh: ctx is null");
+    const char *msg = "";
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = build_linear_bvh(verts_xyz, nverts, tri_idx, ntris, bounds, threshold, depth, ctx->lin, &msg);
+    if (rc) return set_err(ctx, rc == -5 ? PTMI_ERR_DEPTH : PTMI_ERR_INVALID, std::string("ptmi_build_bvh: ") + msg);
+    ctx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return upload_packed(ctx, verts_xyz, nverts, tri_idx, ntris);
+}
+
+extern "C" int ptmi_upload_bvh(ptmi_ctx *ctx, const float *verts_xyz, uint64_t nverts, const uint32_t *tri_idx,
+                               uint64_t ntris, uint64_t n_nodes, const float *node_bounds, const uint8_t *is_leaf,
+                               const uint32_t *tri_offset, const uint32_t *tri_count, const uint32_t *second_child,
+                               uint64_t n_tri_ids, const uint32_t *tri_ids) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_upload_bvh: ctx is null");
+    if (!verts_xyz || !tri_idx || !node_bounds || !is_leaf || !tri_offset || !tri_count || !second_child ||
+        (!tri_ids && n_tri_ids))
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_bvh: null array");
+    for (uint64_t i = 0; i < 3 * ntris; ++i)
+        if (tri_idx[i] >= nverts) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_bvh: triangle index out of range");
+    ctx->lin.nodes.resize(n_nodes);
+    for (uint64_t i = 0; i < n_nodes; ++i) {
+        LinNode &n = ctx->lin.nodes[i];
+        for (int a = 0; a < 3; ++a) { n.minb[a] = node_bounds[6 * i + a]; n.maxb[a] = node_bounds[6 * i + 3 + a]; }
+        n.is_leaf = is_leaf[i] ? 1 : 0;
+        n.tri_offset = tri_offset[i]; n.tri_count = tri_count[i]; n.second_child = second_child[i];
+    }
+    ctx->lin.tri_ids.assign(tri_ids, tri_ids + n_tri_ids);
+    const char *msg = "";
+    int rc = validate_linear_bvh(ctx->lin, ntris, &msg);
+    if (rc) return set_err(ctx, rc == -5 ? PTMI_ERR_DEPTH : PTMI_ERR_INVALID, std::string("ptmi_upload_bvh: ") + msg);
+    ctx->build_ms = 0.0;
+    return upload_packed(ctx, verts_xyz, nverts, tri_idx, ntris);
+}
+
+extern "C" int ptmi_bvh_sizes(ptmi_ctx *ctx, uint64_t *n_nodes, uint64_t *n_tri_ids) {
+    if (!ctx || !n_nodes || !n_tri_ids) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_bvh_sizes: null argument");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_bvh_sizes: no BVH");
+    *n_nodes = ctx->lin.nodes.size();
+    *n_tri_ids = ctx->lin.tri_ids.size();
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_get_linear_bvh(ptmi_ctx *ctx, float *node_bounds, uint8_t *is_leaf, uint32_t *tri_offset,
+                                   uint32_t *tri_count, uint32_t *second_child, uint32_t *tri_ids) {
+    if (!ctx || !node_bounds || !is_leaf || !tri_offset || !tri_count || !second_child || !tri_ids)
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_get_linear_bvh: null argument");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_get_linear_bvh: no BVH");
+    export_linear(ctx->lin, node_bounds, is_leaf, tri_offset, tri_count, second_child, tri_ids);
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_bvh_stats(ptmi_ctx *ctx, PtBvhStats *out) {
+    if (!ctx || !out) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_bvh_stats: null argument");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_bvh_stats: no BVH");
+    fill_stats(ctx->lin, ctx->build_ms, ctx->packed_inner, out);
+    return PTMI_OK;
+}
+
+// ------------------------------------------------------------------------------------ queries
+
+static int dispatch_extend(ptmi_ctx *ctx, const float *o, const float *d, const float *tmax, uint64_t n, int32_t *prim,
+                           float *t, hipStream_t s) {
+    if (n > 0x3FFFFFFFull * WAVE) return set_err(ctx, PTMI_ERR_INVALID, "too many rays in one call");
+    const int dep = ctx->max_depth;
+    if (dep <= 16) launch_extend<16>(ctx, o, d, tmax, n, prim, t, s);
+    else if (dep <= 24) launch_extend<24>(ctx, o, d, tmax, n, prim, t, s);
+    else if (dep <= 32) launch_extend<32>(ctx, o, d, tmax, n, prim, t, s);
+    else if (dep <= 48) launch_extend<48>(ctx, o, d, tmax, n, prim, t, s);
+    else launch_extend<64>(ctx, o, d, tmax, n, prim, t, s);
+    PTMI_HIP(ctx, hipGetLastError());
+    return PTMI_OK;
+}
+static int dispatch_connect(ptmi_ctx *ctx, const float *o, const float *d, const float *tmax, uint64_t n, uint8_t *occ,
+                            hipStream_t s) {
+    if (n > 0x3FFFFFFFull * WAVE) return set_err(ctx, PTMI_ERR_INVALID, "too many rays in one call");
+    const int dep = ctx->max_depth;
+    if (dep <= 16) launch_connect<16>(ctx, o, d, tmax, n, occ, s);
+    else if (dep <= 24) launch_connect<24>(ctx, o, d, tmax, n, occ, s);
+    else if (dep <= 32) launch_connect<32>(ctx, o, d, tmax, n, occ, s);
+    else if (dep <= 48) launch_connect<48>(ctx, o, d, tmax, n, occ, s);
+    else launch_connect<64>(ctx, o, d, tmax, n, occ, s);
+    PTMI_HIP(ctx, hipGetLastError());
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_closest_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax,
+                                    uint64_t n, int32_t *prim_id, float *t, void *stream) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_closest_hit_dev: ctx is null");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_closest_hit_dev: no BVH uploaded");
+    if (n == 0) return PTMI_OK;
+    if (!o_xyz || !d_xyz || !tmax || !prim_id || !t) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_closest_hit_dev: null buffer");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    return dispatch_extend(ctx, o_xyz, d_xyz, tmax, n, prim_id, t, (hipStream_t)stream);
+}
+
+extern "C" int ptmi_any_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n,
+                                uint8_t *occluded, void *stream) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_any_hit_dev: ctx is null");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_any_hit_dev: no BVH uploaded");
+    if (n == 0) return PTMI_OK;
+    if (!o_xyz || !d_xyz || !tmax || !occluded) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_any_hit_dev: null buffer");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    return dispatch_connect(ctx, o_xyz, d_xyz, tmax, n, occluded, (hipStream_t)stream);
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" int ptmi_closest_hit(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n,
+                                int32_t *prim_id, float *t) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_closest_hit: ctx is null");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_closest_hit: no BVH uploaded");
+    if (n == 0) return PTMI_OK;
+    if (!o_xyz || !d_xyz || !tmax || !prim_id || !t) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_closest_hit: null buffer");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t b3 = align_up(n * 12, 256), b1 = align_up(n * 4, 256);
+    int rc = ensure_stage(ctx, 2 * b3 + 3 * b1);
+    if (rc) return rc;
+    char *base = (char *)ctx->d_stage;
+    float *dO = (float *)base, *dD = (float *)(base + b3), *dT = (float *)(base + 2 * b3);
+    int32_t *dP = (int32_t *)(base + 2 * b3 + b1);
+    float *dt = (float *)(base + 2 * b3 + 2 * b1);
+    hipStream_t s = ctx->stream;
+    PTMI_HIP(ctx, hipMemcpyAsync(dO, o_xyz, n * 12, hipMemcpyHostToDevice, s));
+    PTMI_HIP(ctx, hipMemcpyAsync(dD, d_xyz, n * 12, hipMemcpyHostToDevice, s));
+    PTMI_HIP(ctx, hipMemcpyAsync(dT, tmax, n * 4, hipMemcpyHostToDevice, s));
+    rc = dispatch_extend(ctx, dO, dD, dT, n, dP, dt, s);
+    if (rc) return rc;
+    PTMI_HIP(ctx, hipMemcpyAsync(prim_id, dP, n * 4, hipMemcpyDeviceToHost, s));
+    PTMI_HIP(ctx, hipMemcpyAsync(t, dt, n * 4, hipMemcpyDeviceToHost, s));
+    PTMI_HIP(ctx, hipStreamSynchronize(s));
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_any_hit(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n,
+                            uint8_t *occluded) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_any_hit: ctx is null");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_any_hit: no BVH uploaded");
+    if (n == 0) return PTMI_OK;
+    if (!o_xyz || !d_xyz || !tmax || !occluded) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_any_hit: null buffer");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t b3 = align_up(n * 12, 256), b1 = align_up(n * 4, 256);
+    int rc = ensure_stage(ctx, 2 * b3 + 2 * b1);
+    if (rc) return rc;
+    char *base = (char *)ctx->d_stage;
+    float *dO = (float *)base, *dD = (float *)(base + b3), *dT = (float *)(base + 2 * b3);
+    uint8_t *dOcc = (uint8_t *)(base + 2 * b3 + b1);
+    hipStream_t s = ctx->stream;
+    PTMI_HIP(ctx, hipMemcpyAsync(dO, o_xyz, n * 12, hipMemcpyHostToDevice, s));
+    PTMI_HIP(ctx, hipMemcpyAsync(dD, d_xyz, n * 12, hipMemcpyHostToDevice, s));
+    PTMI_HIP(ctx, hipMemcpyAsync(dT, tmax, n * 4, hipMemcpyHostToDevice, s));
+    rc = dispatch_connect(ctx, dO, dD, dT, n, dOcc, s);
+    if (rc) return rc;
+    PTMI_HIP(ctx, hipMemcpyAsync(occluded, dOcc, n, hipMemcpyDeviceToHost, s));
+    PTMI_HIP(ctx, hipStreamSynchronize(s));
+    return PTMI_OK;
+}
+
+// ------------------------------------------------------------------------------------ counters
+
+extern "C" int ptmi_set_counting(ptmi_ctx *ctx, int enabled) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_set_counting: ctx is null");
+    ctx->counting = enabled != 0;
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_reset_counters(ptmi_ctx *ctx) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_reset_counters: ctx is null");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    PTMI_HIP(ctx, hipDeviceSynchronize());
+    PTMI_HIP(ctx, hipMemset(ctx->d_counters, 0, CNT_WORDS * sizeof(unsigned long long)));
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_counters(ptmi_ctx *ctx, PtCounters *out) {
+    if (!ctx || !out) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_counters: null argument");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    PTMI_HIP(ctx, hipDeviceSynchronize());
+    unsigned long long h[CNT_WORDS];
+    PTMI_HIP(ctx, hipMemcpy(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    out->closest_queries = h[CNT_CLOSEST]; out->any_queries = h[CNT_ANY]; out->inner_visits = h[CNT_INNER];
+    out->tri_tests = h[CNT_TRI]; out->leaf_visits = h[CNT_LEAF]; out->diffuse_events = h[CNT_DIFFUSE];
+    out->samples = h[CNT_SAMPLES];
+    return PTMI_OK;
+}

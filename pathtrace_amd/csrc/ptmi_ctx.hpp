@@ -1,0 +1,57 @@
+// ptmi_ctx.hpp -- per-GPU context behind the C ABI (include/ptmi.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ptmi.h"
+#include "bvh_build.hpp"
+#include "trav_device.hpp"
+
+// indices into the device counter block (unsigned long long each)
+enum {
+    CNT_CLOSEST = 0, CNT_ANY = 1, CNT_INNER = 2, CNT_TRI = 3, CNT_LEAF = 4, CNT_DIFFUSE = 5, CNT_SAMPLES = 6,
+    CNT_WORDS = 8
+};
+
+struct ptmi_ctx {
+    int device = 0;
+    std::string err;
+
+    // BVH: host copy in the reference's linear form + device copy in packed form
+    bool have_bvh = false;
+    ptmi::LinearBVH lin;
+    ptmi::BvhStats stats;
+    double build_ms = 0.0;
+    uint64_t packed_inner = 0, packed_tris = 0;
+    int max_depth = 0;
+    float4 *d_nodes = nullptr;
+    float4 *d_tris = nullptr;
+    uint32_t root_ref = ptmi::D_REF_EMPTY_LEAF;
+    std::vector<float> verts;          // kept for the scene upload (emissive sampling, normals)
+    std::vector<uint32_t> tri_idx;
+
+    // staging for the host-pointer entry points (grow-only)
+    void *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    hipStream_t stream = nullptr;
+
+    // work counters
+    bool counting = false;
+    unsigned long long *d_counters = nullptr;
+
+    ptmi::DevBVH dev_bvh() const { return ptmi::DevBVH{d_nodes, d_tris, root_ref}; }
+};
+
+namespace ptmi {
+int set_err(ptmi_ctx *ctx, int code, const std::string &msg);
+int hip_err(ptmi_ctx *ctx, hipError_t e, const char *what);
+int ensure_stage(ptmi_ctx *ctx, size_t bytes);
+}  // namespace ptmi
+
+#define PTMI_HIP(ctx, call)                                              \
+    do {                                                                 \
+        hipError_t e__ = (call);                                         \
+        if (e__ != hipSuccess) return ptmi::hip_err((ctx), e__, #call);  \
+    } while (0)

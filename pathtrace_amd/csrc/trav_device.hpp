@@ -1,0 +1,208 @@
+// trav_device.hpp -- gfx950 device code for BVH traversal (closest-hit "extend", any-hit "connect").
+//
+// Results must equal the reference's Go traversal bit for bit (hit id) -- linear_bvh.go:23-70,
+// 116-250 and utils.go:63-125 -- so every float expression below keeps the reference's operand
+// order, is compiled with -ffp-contract=off (no FMA), uses IEEE division, and reproduces Go's
+// NaN-propagating min/max.  The tree keeps the reference's binary topology and near-first
+// order: only the memory layout changes (both child boxes hoisted into one 64-byte node).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptmi {
+
+constexpr float PT_INF = 3.40282346638528859811704183484516925440e+38f;   // math.MaxFloat32 (linear_bvh.go:9)
+constexpr uint32_t D_REF_LEAF_BIT = 0x80000000u;
+constexpr uint32_t D_REF_EMPTY_LEAF = 0xFFFFFFFFu;
+
+struct DevBVH {
+    const float4 *nodes;   // 4 x float4 per packed inner node
+    const float4 *tris;    // 3 x float4 per packed triangle
+    uint32_t root_ref;
+};
+
+// Go builtin max/min (NaN if either operand is NaN).  The sign of a zero result is not
+// reproduced: slab distances are only ever compared, never output.
+__device__ __forceinline__ float gomaxf(float a, float b) {
+    float m = fmaxf(a, b);
+    return (a != a || b != b) ? __builtin_nanf("") : m;
+}
+__device__ __forceinline__ float gominf(float a, float b) {
+    float m = fminf(a, b);
+    return (a != a || b != b) ? __builtin_nanf("") : m;
+}
+
+// linear_bvh.go:23-70 with inverseDirection hoisted out (it only depends on the ray).
+__device__ __forceinline__ float slab(float minx, float miny, float minz, float maxx, float maxy, float maxz,
+                                      float ox, float oy, float oz, float ix, float iy, float iz, float step) {
+    float t1 = (minx - ox) * ix, t2 = (maxx - ox) * ix;
+    float tmin = t1 > t2 ? t2 : t1;
+    float tmax = t1 > t2 ? t1 : t2;
+    t1 = (miny - oy) * iy; t2 = (maxy - oy) * iy;
+    float a = t1 > t2 ? t2 : t1, b = t1 > t2 ? t1 : t2;
+    tmin = gomaxf(tmin, a); tmax = gominf(tmax, b);
+    t1 = (minz - oz) * iz; t2 = (maxz - oz) * iz;
+    a = t1 > t2 ? t2 : t1; b = t1 > t2 ? t1 : t2;
+    tmin = gomaxf(tmin, a); tmax = gominf(tmax, b);
+    if (tmin > gominf(tmax, step) || tmax < 0.0f) return PT_INF;
+    return gomaxf(0.0f, tmin);
+}
+
+// utils.go:63-125.  Returns true and t on a hit.
+__device__ __forceinline__ bool segment_triangle(float ox, float oy, float oz, float dx, float dy, float dz,
+                                                 float step, float ax, float ay, float az, float bx, float by,
+                                                 float bz, float cx, float cy, float cz, float &t_out) {
+    const float EPS = (float)1e-6;
+    const float ONE_PLUS_EPS = (float)1.000001;
+    float e1x = bx - ax, e1y = by - ay, e1z = bz - az;
+    float e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
+    float px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
+    float det = (e1x * px + e1y * py) + e1z * pz;
+    if (fabsf(det) < EPS) return false;
+    float inv = 1.0f / det;
+    float tx = ox - ax, ty = oy - ay, tz = oz - az;
+    float u = ((tx * px + ty * py) + tz * pz) * inv;
+    if (u < -EPS || u > ONE_PLUS_EPS) return false;
+    float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+    float v = ((dx * qx + dy * qy) + dz * qz) * inv;
+    if (v < -EPS || u + v > ONE_PLUS_EPS) return false;
+    float t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;
+    if (t <= EPS || t > step) return false;
+    t_out = t;
+    return true;
+}
+
+// linear_bvh.go:173-200
+__device__ __forceinline__ bool shadow_triangle(float ox, float oy, float oz, float dx, float dy, float dz,
+                                                float tmax, float ax, float ay, float az, float bx, float by,
+                                                float bz, float cx, float cy, float cz) {
+    float e1x = bx - ax, e1y = by - ay, e1z = bz - az;
+    float e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
+    float hx = dy * e2z - dz * e2y, hy = dz * e2x - dx * e2z, hz = dx * e2y - dy * e2x;
+    float a = (e1x * hx + e1y * hy) + e1z * hz;
+    if (fabsf(a) < (float)0.00001) return false;
+    float sx = ox - ax, sy = oy - ay, sz = oz - az;
+    float u = ((sx * hx + sy * hy) + sz * hz) / a;
+    if (u < 0.0f || u > 1.0f) return false;
+    float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;
+    float v = ((dx * qx + dy * qy) + dz * qz) / a;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = ((e2x * qx + e2y * qy) + e2z * qz) / a;
+    return t > (float)0.00001 && t < tmax;
+}
+
+struct TravCounters {
+    uint32_t inner = 0, tri = 0, leaf = 0;
+};
+
+// Per-lane traversal stack in LDS, laid out [entry][lane of the workgroup]: a lane's bank
+// depends only on its lane id, so pushes/pops at different depths never conflict.
+template <int BLOCK>
+struct LdsStack {
+    uint32_t *base;   // &smem[threadIdx.x]
+    int sp = 0;
+    __device__ __forceinline__ void push(uint32_t v) { base[sp * BLOCK] = v; ++sp; }
+    __device__ __forceinline__ uint32_t pop() { --sp; return base[sp * BLOCK]; }
+    __device__ __forceinline__ bool empty() const { return sp == 0; }
+};
+
+// CheckIntersection (linear_bvh.go:116-170).  prim = -1 on a miss.
+template <int BLOCK, bool COUNT>
+__device__ __forceinline__ void closest_hit(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
+                                            float dx, float dy, float dz, float step, int &prim_out, float &t_out,
+                                            TravCounters &cnt) {
+    // Inverse() (vec3.go:118-124); the reference recomputes it per box with the same result
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    LdsStack<BLOCK> st{stack_base};
+    float best_t = step;
+    int best = -1;
+    uint32_t cur = bvh.root_ref;
+    for (;;) {
+        if (!(cur & D_REF_LEAF_BIT)) {
+            if (COUNT) cnt.inner++;
+            const float4 *p = bvh.nodes + (size_t)cur * 4;
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            // q0 = c0min.xyz c0max.x | q1 = c0max.yz c1min.xy | q2 = c1min.z c1max.xyz | q3 = ref0 ref1 - -
+            float d1 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, best_t);
+            float d2 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, best_t);
+            uint32_t i = __float_as_uint(q3.x), j = __float_as_uint(q3.y);
+            if (d1 > d2) { uint32_t ti = i; i = j; j = ti; float td = d1; d1 = d2; d2 = td; }   // :148-151
+            if (d1 == PT_INF) {                                                                  // :152-154
+                if (st.empty()) break;
+                cur = st.pop();
+                continue;
+            }
+            if (d2 < best_t) st.push(j);                                                         // :156-159
+            cur = i;                                                                             // :160 (pushed, popped next)
+            continue;
+        }
+        if (cur != D_REF_EMPTY_LEAF) {
+            if (COUNT) cnt.leaf++;
+            const float4 *p = bvh.tris + (size_t)(cur & 0x7FFFFFFFu) * 3;
+            for (;;) {
+                const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+                // r0 = A.xyz B.x | r1 = B.yz C.xy | r2 = C.z prim nleft pad
+                if (COUNT) cnt.tri++;
+                float t;
+                bool hit = segment_triangle(ox, oy, oz, dx, dy, dz, best_t, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y,
+                                            r1.z, r1.w, r2.x, t);
+                if (hit && t < best_t && t > 0.0f) { best_t = t; best = (int)__float_as_uint(r2.y); }   // :133-136
+                if (__float_as_uint(r2.z) == 0u) break;
+                p += 3;
+            }
+        } else if (COUNT) {
+            cnt.leaf++;
+        }
+        if (st.empty()) break;
+        cur = st.pop();
+    }
+    prim_out = best;
+    t_out = best >= 0 ? best_t : 0.0f;
+}
+
+// QuickCheckIntersection (linear_bvh.go:202-250)
+template <int BLOCK, bool COUNT>
+__device__ __forceinline__ bool any_hit(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
+                                        float dx, float dy, float dz, float step, TravCounters &cnt) {
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    LdsStack<BLOCK> st{stack_base};
+    uint32_t cur = bvh.root_ref;
+    for (;;) {
+        if (!(cur & D_REF_LEAF_BIT)) {
+            if (COUNT) cnt.inner++;
+            const float4 *p = bvh.nodes + (size_t)cur * 4;
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            float d1 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, step);
+            float d2 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, step);
+            uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
+            bool h1 = d1 < step, h2 = d2 < step;
+            if (h1 && h2) {                              // :226-238 push far first, near on top
+                if (d1 < d2) { st.push(r1); cur = r0; } else { st.push(r0); cur = r1; }
+                continue;
+            } else if (h1) { cur = r0; continue; }       // :239-241
+            else if (h2) { cur = r1; continue; }         // :242-244
+            if (st.empty()) return false;
+            cur = st.pop();
+            continue;
+        }
+        if (cur != D_REF_EMPTY_LEAF) {
+            if (COUNT) cnt.leaf++;
+            const float4 *p = bvh.tris + (size_t)(cur & 0x7FFFFFFFu) * 3;
+            for (;;) {
+                const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+                if (COUNT) cnt.tri++;
+                if (shadow_triangle(ox, oy, oz, dx, dy, dz, step, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w,
+                                    r2.x))
+                    return true;
+                if (__float_as_uint(r2.z) == 0u) break;
+                p += 3;
+            }
+        } else if (COUNT) {
+            cnt.leaf++;
+        }
+        if (st.empty()) return false;
+        cur = st.pop();
+    }
+}
+
+}  // namespace ptmi

@@ -1,0 +1,102 @@
+"""GPU parity: HIP extend/connect kernels (through the C ABI) vs the CPU oracle.
+
+Bar (BASELINE.json north_star): primitive id bit-exact, t within 1e-5 relative -- we require t
+bit-exact too, since the kernel keeps the reference's operation order with FMA contraction off.
+"""
+import numpy as np
+import pytest
+
+from pathtrace_amd import BuildBVH, ConstructLinearBVH, scenes
+import oracle_lib
+from helpers import random_rays, adversarial_rays, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(bvh, orc, o, d, tmax, label):
+    hit, t, prim = bvh.CheckIntersection((o, d), tmax)
+    oprim, ot, _ = orc.closest_hit(o, d, tmax)
+    nbad = int((prim != oprim).sum())
+    assert nbad == 0, f"{label}: {nbad}/{len(prim)} closest-hit prim ids differ"
+    assert bits_equal(t, ot), f"{label}: t differs in {(t.view(np.uint32) != ot.view(np.uint32)).sum()} rays"
+    occ = bvh.QuickCheckIntersection((o, d), tmax)
+    oocc, _ = orc.any_hit(o, d, tmax)
+    assert np.array_equal(occ, oocc), f"{label}: {(occ != oocc).sum()} any-hit results differ"
+    return hit
+
+
+@pytest.mark.parametrize("ntris,seed", [(0, 1), (1, 2), (3, 3), (4, 4), (5, 5), (37, 6), (2000, 7), (70000, 8)])
+def test_soup_parity(gpu_ctx, ntris, seed):
+    if ntris == 0:
+        v = np.zeros((3, 3), np.float32); f = np.zeros((0, 3), np.uint32)
+    else:
+        v, f = scenes.make_soup(ntris, seed)
+    box = BuildBVH(v, f)
+    bvh = ConstructLinearBVH(box, ctx=gpu_ctx)
+    orc = oracle_lib.OracleBVH(v, f, linear=box.linear())
+    nr = 20000 if ntris < 70000 else 200000
+    vv = v if ntris else np.array([[-1, -1, -1], [1, 1, 1]], np.float32)
+    o, d = random_rays(vv, nr, seed + 100)
+    hit = _check(bvh, orc, o, d, 1000.0, f"soup{ntris}/random")
+    if ntris >= 2000:
+        assert hit.mean() > 0.05
+    if ntris:
+        o, d, tmax = adversarial_rays(v, f, 4096, seed + 200)
+        _check(bvh, orc, o, d, tmax, f"soup{ntris}/adversarial")
+
+
+def test_scene_parity_with_camera_rays(gpu_ctx):
+    sc = scenes.bunny_scene(small=False)
+    box = BuildBVH(sc.verts, sc.tris)
+    bvh = ConstructLinearBVH(box, ctx=gpu_ctx)
+    orc = oracle_lib.OracleBVH(sc.verts, sc.tris, linear=box.linear())
+    o, d = scenes.camera_rays(sc.camera, 256, 256)
+    hit = _check(bvh, orc, o, d, 1000.0, "bunny/primary")
+    assert hit.mean() > 0.3
+    prim = bvh.CheckIntersection((o, d), 1000.0)[2]
+    t = bvh.CheckIntersection((o, d), 1000.0)[1]
+    o2, d2 = scenes.cosine_bounce_rays(sc.verts, sc.tris, o, d, prim, t, seed=42)
+    _check(bvh, orc, o2, d2, 1000.0, "bunny/secondary")
+    # short segments (the reference marches in stepSize segments, tracer.go:34-35)
+    _check(bvh, orc, o, d, 2.5, "bunny/short-step")
+
+
+def test_counters_match_oracle(gpu_ctx):
+    v, f = scenes.make_soup(20000, 11)
+    box = BuildBVH(v, f)
+    bvh = ConstructLinearBVH(box, ctx=gpu_ctx)
+    orc = oracle_lib.OracleBVH(v, f, linear=box.linear())
+    o, d = random_rays(v, 50000, 5)
+    bvh.set_counting(True)
+    bvh.reset_counters()
+    bvh.CheckIntersection((o, d), 1000.0)
+    c = bvh.counters()
+    _, _, oc = orc.closest_hit(o, d, 1000.0)
+    assert (c.closest_queries, c.inner_visits, c.tri_tests, c.leaf_visits) == \
+        (50000, oc["inner_visits"], oc["tri_tests"], oc["leaf_visits"])
+    bvh.reset_counters()
+    bvh.QuickCheckIntersection((o, d), 1000.0)
+    c = bvh.counters()
+    _, oc = orc.any_hit(o, d, 1000.0)
+    assert (c.any_queries, c.inner_visits, c.tri_tests, c.leaf_visits) == \
+        (50000, oc["inner_visits"], oc["tri_tests"], oc["leaf_visits"])
+    bvh.set_counting(False)
+
+
+def test_upload_prebuilt_tree_and_errors(gpu_ctx):
+    from pathtrace_amd import UploadLinearBVH, PtmiError, Context, LinearBVH
+    v, f = scenes.make_soup(3000, 21)
+    box = BuildBVH(v, f)
+    bvh = UploadLinearBVH(v, f, box.linear(), ctx=gpu_ctx)
+    orc = oracle_lib.OracleBVH(v, f)        # literal oracle builder this time
+    o, d = random_rays(v, 10000, 6)
+    _check(bvh, orc, o, d, 1000.0, "uploaded")
+    lin = box.linear()
+    lin.second_child = lin.second_child.copy(); lin.second_child[0] = 10 ** 9
+    with pytest.raises(PtmiError):
+        UploadLinearBVH(v, f, lin, ctx=gpu_ctx)
+    fresh = Context(0)
+    with pytest.raises(PtmiError) as e:
+        LinearBVH(fresh).CheckIntersection((o, d), 1.0)
+    assert e.value.code == -4
+    fresh.close()
