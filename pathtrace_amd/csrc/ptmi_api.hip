@@ -269,8 +269,11 @@ extern "C" int ptmi_build_bvh(ptmi_ctx *ctx, const float *verts_xyz, uint64_t nv
     if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_build_bvh: ctx is null");
     const char *msg = "";
     auto t0 = std::chrono::steady_clock::now();
-    int rc = build_linear_bvh(verts_xyz, nverts, tri_idx, ntris, bounds, threshold, depth, ctx->lin, &msg);
+    LinearBVH lin;
+    int rc = build_linear_bvh(verts_xyz, nverts, tri_idx, ntris, bounds, threshold, depth, lin, &msg);
     if (rc) return set_err(ctx, rc == -5 ? PTMI_ERR_DEPTH : PTMI_ERR_INVALID, std::string("ptmi_build_bvh: ") + msg);
+    ctx->lin.nodes.swap(lin.nodes);
+    ctx->lin.tri_ids.swap(lin.tri_ids);
     ctx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return upload_packed(ctx, verts_xyz, nverts, tri_idx, ntris);
 }
@@ -285,17 +288,20 @@ extern "C" int ptmi_upload_bvh(ptmi_ctx *ctx, const float *verts_xyz, uint64_t n
         return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_bvh: null array");
     for (uint64_t i = 0; i < 3 * ntris; ++i)
         if (tri_idx[i] >= nverts) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_bvh: triangle index out of range");
-    ctx->lin.nodes.resize(n_nodes);
+    LinearBVH lin;
+    lin.nodes.resize(n_nodes);
     for (uint64_t i = 0; i < n_nodes; ++i) {
-        LinNode &n = ctx->lin.nodes[i];
+        LinNode &n = lin.nodes[i];
         for (int a = 0; a < 3; ++a) { n.minb[a] = node_bounds[6 * i + a]; n.maxb[a] = node_bounds[6 * i + 3 + a]; }
         n.is_leaf = is_leaf[i] ? 1 : 0;
         n.tri_offset = tri_offset[i]; n.tri_count = tri_count[i]; n.second_child = second_child[i];
     }
-    ctx->lin.tri_ids.assign(tri_ids, tri_ids + n_tri_ids);
+    lin.tri_ids.assign(tri_ids, tri_ids + n_tri_ids);
     const char *msg = "";
-    int rc = validate_linear_bvh(ctx->lin, ntris, &msg);
+    int rc = validate_linear_bvh(lin, ntris, &msg);
     if (rc) return set_err(ctx, rc == -5 ? PTMI_ERR_DEPTH : PTMI_ERR_INVALID, std::string("ptmi_upload_bvh: ") + msg);
+    ctx->lin.nodes.swap(lin.nodes);
+    ctx->lin.tri_ids.swap(lin.tri_ids);
     ctx->build_ms = 0.0;
     return upload_packed(ctx, verts_xyz, nverts, tri_idx, ntris);
 }

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Profile bench.py on the GPU box: one kernel-trace pass + separate PMC passes (rocprofv3 does not
+# split counters over passes; each block's slot limit is respected per pass -- MI355X_MICROARCH.md).
+# usage: tools/profile_bench.sh <outdir> [bench args...]
+set -u
+OUT=${1:-gpurun_out/prof}; shift || true
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p "$OUT"
+run() {  # name, rocprof options...
+  local name=$1; shift
+  timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS \
+      > "$OUT/$name.json" 2> "$OUT/$name.err"
+  local rc=$?
+  echo "$name rc=$rc"
+  return $rc
+}
+run kt --kernel-trace --stats || exit 1
+run pmc_fetch --pmc FETCH_SIZE GRBM_GUI_ACTIVE || exit 1
+run pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum || exit 1
+run pmc_sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY || exit 1
+run pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_LEVEL_WAVES TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum || exit 1
+echo done
