@@ -1,0 +1,91 @@
+"""Host builder (binned, product code) vs the literal O(387 N) restatement of bvh.go in the oracle:
+the LinearBVH arrays must be identical bit for bit (topology decides closest-hit tie-breaks)."""
+import numpy as np
+import pytest
+
+from pathtrace_amd import BuildBVH, PtmiError, scenes
+import oracle_lib
+from helpers import bits_equal
+
+
+def _same(a, b):
+    return (bits_equal(a.node_bounds, b.node_bounds) and bits_equal(a.is_leaf, b.is_leaf)
+            and bits_equal(a.tri_offset, b.tri_offset) and bits_equal(a.tri_count, b.tri_count)
+            and bits_equal(a.second_child, b.second_child) and bits_equal(a.tri_ids, b.tri_ids))
+
+
+def _compare(v, f, bounds=(-1000, 1000, -1000, 1000, -1000, 1000), threshold=4, depth=42):
+    box = BuildBVH(v, f, *bounds, threshold, depth)
+    a = box.linear()
+    b = oracle_lib.OracleBVH(v, f, bounds, threshold, depth).linear()
+    assert a.node_bounds.shape == b.node_bounds.shape, (a.node_bounds.shape, b.node_bounds.shape)
+    assert _same(a, b)
+    return box, a
+
+
+@pytest.mark.parametrize("ntris,seed", [(1, 1), (4, 2), (5, 3), (6, 4), (33, 5), (64, 6), (65, 7), (300, 8),
+                                        (3000, 9), (20000, 10)])
+def test_soup_matches_literal_builder(ntris, seed):
+    v, f = scenes.make_soup(ntris, seed)
+    box, a = _compare(v, f)
+    st = box.GetStats()
+    assert st.total_triangles == ntris and st.linear_nodes == a.node_bounds.shape[0]
+    assert st.total_nodes == st.total_leafs          # the reference's GetStats counts leaves only (bvh.go:123)
+    assert sorted(a.tri_ids.tolist()) == list(range(ntris))
+
+
+def test_scene_meshes_match():
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    _compare(sc.verts, sc.tris)
+    bh = scenes.blackhole_scene(segments=64)
+    _compare(bh.verts, bh.tris)
+
+
+@pytest.mark.parametrize("threshold,depth", [(4, 0), (4, 1), (4, 3), (1, 42), (0, 42), (-1, 6), (16, 42), (4, 62)])
+def test_threshold_and_depth_stops(threshold, depth):
+    v, f = scenes.make_soup(700, 12)
+    box, a = _compare(v, f, threshold=threshold, depth=depth)
+    assert box.GetStats().max_depth <= depth + 1
+
+
+def test_tight_and_offset_root_bounds():
+    v, f = scenes.make_soup(1500, 13)
+    lo, hi = v.min(0), v.max(0)
+    _compare(v, f, bounds=(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]))
+    _compare(v, f, bounds=(-3.0, 50.0, -1.0, 2.0, 0.5, 1000.0))
+    _compare(v, f, bounds=(0.0, 0.0, 0.0, 0.0, 0.0, 0.0))        # degenerate root box: all mids equal
+
+
+def test_degenerate_geometry():
+    # many coincident triangles: the SAH stop / depth stop yields a big leaf
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    v = np.tile(tri, (40, 1)); f = np.arange(120, dtype=np.uint32).reshape(-1, 3)
+    box, a = _compare(v, f)
+    assert box.GetStats().max_tris >= 5
+    # zero-area and axis-aligned flat triangles, negative zero coordinates
+    v = np.array([[0, 0, 0], [0, 0, 0], [0, 0, 0], [-0.0, 1, 2], [3, 1, -0.0], [1, 1, 5], [2, 2, 2], [2, 2, 2],
+                  [4, 4, 4], [-5, 0, 1], [-5, 3, 1], [-5, 1, 7]], np.float32)
+    f = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11], [0, 4, 8], [1, 5, 9], [2, 6, 10]], np.uint32)
+    _compare(v, f)
+    # triangles straddling / far outside the root bounds
+    v, f = scenes.make_soup(200, 14)
+    _compare((v * np.float32(400.0)).astype(np.float32), f)
+
+
+def test_non_finite_vertices_follow_go_semantics():
+    v, f = scenes.make_soup(120, 15)
+    v = v.copy(); v[5, 1] = np.nan; v[17, 0] = np.inf; v[29, 2] = -np.inf
+    _compare(v, f)
+
+
+def test_error_paths():
+    v, f = scenes.make_soup(10, 16)
+    with pytest.raises(PtmiError) as e:
+        BuildBVH(v, f, depth=63)
+    assert e.value.code == -5
+    bad = f.copy(); bad[0, 0] = v.shape[0]
+    with pytest.raises(PtmiError):
+        BuildBVH(v, bad)
+    empty = BuildBVH(v, np.zeros((0, 3), np.uint32))
+    a = empty.linear()
+    assert a.node_bounds.shape[0] == 1 and a.is_leaf[0] == 1 and a.tri_count[0] == 0

@@ -100,3 +100,25 @@ def test_upload_prebuilt_tree_and_errors(gpu_ctx):
         LinearBVH(fresh).CheckIntersection((o, d), 1.0)
     assert e.value.code == -4
     fresh.close()
+
+
+import glob
+import os
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_golden_vectors_on_gpu(gpu_ctx, path):
+    """HIP path vs the committed golden vectors (inputs + expected outputs, tests/golden/)."""
+    g = np.load(path)
+    bvh = ConstructLinearBVH(BuildBVH(g["verts"], g["tris"]), ctx=gpu_ctx)
+    hit, t, prim = bvh.CheckIntersection((g["o"], g["d"]), g["tmax"])
+    assert np.array_equal(prim, g["prim"]) and bits_equal(t, g["t"])
+    occ = bvh.QuickCheckIntersection((g["o"], g["d"]), g["tmax"])
+    assert np.array_equal(occ, g["occluded"].astype(bool))
+    bvh.set_counting(True); bvh.reset_counters()
+    bvh.CheckIntersection((g["o"], g["d"]), g["tmax"])
+    c = bvh.counters()
+    bvh.set_counting(False)
+    assert [c.inner_visits, c.tri_tests, c.leaf_visits] == g["closest_counters"].tolist()
