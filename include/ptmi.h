@@ -130,6 +130,99 @@ int ptmi_set_counting(ptmi_ctx *ctx, int enabled);
 int ptmi_reset_counters(ptmi_ctx *ctx);
 int ptmi_counters(ptmi_ctx *ctx, PtCounters *out);   /* synchronises the device */
 
+/* ------------------------------------------------------------------ scene + integrator */
+
+/* Material record the integrator reads (obj.go:63-79).  The reference detects glass and the
+ * accretion disk by material NAME (tracer.go:49 prefix "Glass", :95 == "AccretionDisk"); the host
+ * flattens that to flags.  64 bytes. */
+enum { PTMI_MAT_GLASS = 1, PTMI_MAT_ACCRETION = 2 };
+typedef struct {
+    float kd[3];        /* Diffuse   */
+    float ks[3];        /* Specular  */
+    float ke[3];        /* Emissive  */
+    float ni;           /* Refraction */
+    float ns;           /* Shininess */
+    uint32_t flags;
+    uint32_t pad[4];
+} PtMaterial;
+
+/* lights.go:11-15 (Sun: vec = Direction, used un-normalised as the reference does) and :32-35
+ * (PointLight: vec = Position).  48 bytes. */
+enum { PTMI_LIGHT_SUN = 0, PTMI_LIGHT_POINT = 1 };
+typedef struct {
+    int32_t kind;
+    float color[3];
+    float vec[3];
+    float intensity;
+    float pad[4];
+} PtLight;
+
+/* skybox.go: nil / SolidColorSkybox (colour in `horizon`) / GradientSkybox / ImageSkybox (equirect
+ * RGB16 image passed beside the struct).  64 bytes. */
+enum { PTMI_SKY_NONE = 0, PTMI_SKY_SOLID = 1, PTMI_SKY_GRADIENT = 2, PTMI_SKY_IMAGE = 3 };
+typedef struct {
+    int32_t kind;
+    float horizon[3], zenith[3], ground[3];
+    float intensity;
+    int32_t image_width, image_height;
+    float pad[3];
+} PtSky;
+
+/* BlackHole.go:10-14, 166-170 (only BlackHoles[0] is used by the reference: tracer.go:28-31). */
+typedef struct {
+    float position[3];
+    float rs;
+    int32_t has_disk;
+    float disk_inner, disk_outer;
+    float pad;
+} PtBlackHole;
+
+/* camera.go:9-15 */
+typedef struct {
+    float position[3], forward[3], right[3], up[3];
+    float frustum_distance;
+} PtCamera;
+
+/* The literals of main.go:441-452 that TraceRay receives positionally (main.go:875), plus the seed
+ * of the counter-based RNG that replaces Go's unseeded global math/rand. */
+typedef struct {
+    int32_t width, height;      /* full image size: pixel (X,Y) -> ray as main.go:862-874 */
+    int32_t bounces, scatter_rays, max_steps;
+    float ambient, step_size;
+    uint32_t seed;
+} PtParams;
+
+/* Replaces the scene-side arguments of TraceRay (vnmu *VNMU, scene *Scene: tracer.go:15,
+ * vnmu.go:8-13, scene.go:3-9), flattened once (the Go pointer graphs cannot cross cgo).  Needs a
+ * BVH (the vertex / index arrays given to ptmi_build_bvh are reused).  corner_normals: 3 per
+ * triangle, in triangle order (vnmu.Normals); tri_material: one per triangle (vnmu.Materials,
+ * as an index); emissive triangles are derived as renderer.go:311-321 does.  sky_image: RGB16
+ * rows (image_height x image_width x 3) or NULL; blackhole: NULL when the scene has none. */
+int ptmi_upload_scene(ptmi_ctx *ctx, const PtMaterial *materials, uint64_t nmaterials, const uint32_t *tri_material,
+                      const float *corner_normals, const PtLight *lights, uint64_t nlights, const PtSky *sky,
+                      const uint16_t *sky_image, const PtBlackHole *blackhole);
+
+/* Replaces the body of the `calculate` worker (main.go:832-899) for one tile: for every pixel of the
+ * rectangle (x0,y0,w,h) trace samples [spp_begin, spp_begin+spp_count) -- camera ray (main.go:862-874),
+ * TraceRay (tracer.go:15) -- and ADD them, in sample order, into accum_rgb[w*h*3] and counts[w*h]:
+ * the R,G,B,SampleCount sums of Pixel.AddSample (renderer.go:29,59-61).  Host buffers; synchronous. */
+int ptmi_render(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t x0, int32_t y0, int32_t w,
+                int32_t h, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb, uint32_t *counts);
+/* Same with device buffers; work is enqueued on `stream`, but the call itself waits for the
+ * wavefront loop's queue counters, so it returns when the rectangle is done. */
+int ptmi_render_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t x0, int32_t y0, int32_t w,
+                    int32_t h, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb, uint32_t *counts,
+                    void *stream);
+/* Per-sample radiance without accumulation: out[(pixel*spp_count + s)*3], host buffer. */
+int ptmi_render_samples(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t x0, int32_t y0,
+                        int32_t w, int32_t h, uint32_t spp_begin, uint32_t spp_count, float *out_rgb);
+
+/* Replaces Vec3.ToRGBA (vec3.go:95-106) + the write-back of main.go:886-896: mean = sum/count,
+ * sqrt-gamma, clamp, truncating uint8, written mirrored to column width - X (X = 0 is dropped and
+ * column 0 never written, as in the reference).  rgba: width*height*4 bytes, host, caller-initialised. */
+int ptmi_to_rgba(ptmi_ctx *ctx, const float *accum_rgb, const uint32_t *counts, int32_t width, int32_t height,
+                 uint8_t *rgba);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,9 @@ struct ptmi_ctx {
     size_t stage_bytes = 0;
     hipStream_t stream = nullptr;
 
+    // scene + wavefront integrator state (ptmi_render.hip)
+    struct RenderState *render = nullptr;
+
     // work counters
     bool counting = false;
     unsigned long long *d_counters = nullptr;

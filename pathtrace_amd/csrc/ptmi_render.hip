@@ -1,6 +1,930 @@
-// ptmi_render.hip -- wavefront integrator (generate / extend / shade / connect / accumulate).
+// ptmi_render.hip -- wavefront (queue-based) integrator: generate / extend / shade / connect / accumulate.
+//
+// Replaces the reference's recursive TraceRay (tracer.go:15-264) and its callees.  The recursion
+// branches (a glass hit first traces the refraction subtree, then shades the same hit diffuse or
+// reflective; tracer.go:49-91, :115-215) and shares one mutable RefractiveIndexTracker across sibling
+// subtrees, so each primary sample walks its own recursion tree in the reference's depth-first order
+// with an explicit frame stack in HBM; what is batched across samples are the expensive steps:
+//   generate : camera rays (main.go:861-874) into free path slots
+//   extend   : closest-hit march per path (tracer.go:34-35, 226-256; BVH walk = trav_device.hpp)
+//   shade    : the per-hit logic of TraceRay / HandleDiffuseMaterial / HandleReflectiveMaterial, run
+//              until the path needs another extend, a batch of shadow rays, or is finished
+//   connect  : any-hit for the shadow-ray queue (QuickCheckIntersection, linear_bvh.go:202)
+//   accumulate : per-pixel sums in sample order (Pixel.AddSample, renderer.go:59-61)
+// Queues are compacted with one atomic per wave (ballot + popcount); finished paths are re-filled
+// with fresh samples so the pool stays full.  All path state is SoA ([field][slot]) so that a wave's
+// accesses coalesce.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
 #include "ptmi_ctx.hpp"
+#include "shade_device.hpp"
+
+using namespace ptmi;
+
+namespace {
+
+constexpr int WAVE = 64;
+
+// ---- frame fields (one frame per TraceRay invocation on the explicit recursion stack) ----------
+enum {
+    F_BOUNCES = 0, F_BINDEX = 1, F_FLAGS = 2, F_ENERGY = 3, F_LN = 4,      // inputs of TraceRay (:15)
+    F_RO = 7, F_RD = 10, F_T = 13, F_PRIM = 14,                            // the hit being shaded
+    F_DG = 15, F_DIFF = 16,                                                // doppler*gravity, diffuse component
+    F_REFR = 19, F_DIRECT = 22, F_SUM = 25, F_S = 28, F_PHASE = 29, F_NEED = 30,
+    NF = 31
+};
+enum { FL_SPECULAR = 1, FL_FLIPPED = 2 };
+// what the top frame is waiting for
+enum { PH_EXTEND = 0, PH_REFR_WAIT = 1, PH_SHADOW_WAIT = 2, PH_GI_WAIT = 3, PH_REFL_WAIT = 4 };
+enum { HS_MISS = 0, HS_HIT = 1, HS_HORIZON = 2 };
+// queue counters
+enum { Q_EXT = 0, Q_SHADOW_PATHS = 1, Q_SHADOW_RAYS = 2, Q_FREE = 3, Q_WORDS = 8 };
+
+struct DevScene {
+    const float *verts; const uint32_t *tri_idx; const float *normals; const uint32_t *tri_mat;
+    const PtMaterial *mats; const uint32_t *emissive; uint32_t nemissive;
+    const PtLight *lights; uint32_t nlights;
+    PtSky sky; const uint16_t *sky_img;
+    PtBlackHole bh; int has_bh;
+};
+
+struct RenderArgs {
+    PtCamera cam;
+    PtParams p;
+    int x0, y0, w, h;
+    uint32_t spp_begin, spp_chunk;       // this batch covers samples [spp_begin, spp_begin+spp_chunk) of every pixel
+    uint64_t total;                      // w*h*spp_chunk
+};
+
+// Path pool, SoA.  All arrays have `cap` slots.
+struct Pool {
+    uint32_t cap;
+    int nframes, ntrk, nshadow;          // bounces+1, tracker history capacity, nlights+2
+    uint32_t *sid, *rng_key, *rng_ctr;
+    int32_t *depth;
+    uint32_t *trk_len; float *trk;       // [ntrk][cap]
+    float *ro, *rd;                      // [3][cap] current ray (updated by extend while marching)
+    int32_t *hstatus, *hprim; float *ht, *vt0, *vt1;
+    float *fr;                           // [nframes*NF][cap]
+    float *sh_contrib;                   // [nshadow*3][cap]
+    uint8_t *sh_occ;                     // [nshadow][cap]
+    // queues
+    uint32_t *q_ext[2];                  // extend queue (double buffered)
+    uint32_t *q_shpath[2];               // paths waiting for their shadow rays
+    float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, bits(target))
+    uint32_t *q_free;                    // slots that finished in the last shade pass
+    unsigned long long *qcnt;            // Q_WORDS counters
+    float *out;                          // per-sample radiance [total][3]
+};
+
+__device__ __forceinline__ uint32_t wave_append(unsigned long long *counter, bool pred) {
+    // one atomic per wave: ballot, popcount, prefix by lane
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    int lane = threadIdx.x & 63;
+    uint32_t total = (uint32_t)__popcll(mask);
+    unsigned long long base = 0;
+    int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = atomicAdd(counter, (unsigned long long)total);
+    base = __shfl((long long)base, leader);
+    uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    return (uint32_t)base + prefix;
+}
+
+// ------------------------------------------------------------------------------------------ generate
+// main.go:861-874 + the TraceRay call of :875 (bounceIndex 0, lastSurfaceNormal {}, not specular,
+// NewRefractiveIndexTracker(1.0), energy 1.0)
+__global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, const uint32_t *slots, uint32_t n,
+                                                       uint64_t first_sample, unsigned long long *qcnt_next_ext,
+                                                       uint32_t *q_ext_next) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = i < n;
+    uint32_t slot = 0;
+    if (live) {
+        slot = slots ? slots[i] : i;
+        uint64_t sid = first_sample + i;
+        uint32_t pix = (uint32_t)(sid / ra.spp_chunk), s = (uint32_t)(sid % ra.spp_chunk);
+        int X = ra.x0 + (int)(pix % (uint32_t)ra.w), Y = ra.y0 + (int)(pix / (uint32_t)ra.w);
+        Rng rng = rng_init(ra.p.seed, (uint32_t)(Y * ra.p.width + X), ra.spp_begin + s);
+        float rx = ((float)X + rng_f32(rng)) / (float)ra.p.width;
+        float ry = ((float)Y + rng_f32(rng)) / (float)ra.p.height;
+        float px = (rx - 0.5f) * 2.0f, py = (ry - 0.5f) * 2.0f;
+        V3 pos = mk(ra.cam.position), fwd = mk(ra.cam.forward), right = mk(ra.cam.right), up = mk(ra.cam.up);
+        V3 rayOrigin = add(add(add(pos, scale(fwd, ra.cam.frustum_distance)), scale(up, py)), scale(right, px));
+        V3 d = normalize(mk(rayOrigin.x - pos.x, rayOrigin.y - pos.y, rayOrigin.z - pos.z));
+        const uint32_t cap = pl.cap;
+        pl.sid[slot] = (uint32_t)sid;
+        pl.rng_key[slot] = rng.key; pl.rng_ctr[slot] = rng.ctr;
+        pl.depth[slot] = 0;
+        pl.trk_len[slot] = 1; pl.trk[slot] = 1.0f;
+        pl.ro[slot] = pos.x; pl.ro[cap + slot] = pos.y; pl.ro[2 * cap + slot] = pos.z;
+        pl.rd[slot] = d.x; pl.rd[cap + slot] = d.y; pl.rd[2 * cap + slot] = d.z;
+        float *f = pl.fr + slot;
+        ((int32_t *)f)[(size_t)F_BOUNCES * cap] = ra.p.bounces;
+        ((int32_t *)f)[(size_t)F_BINDEX * cap] = 0;
+        ((uint32_t *)f)[(size_t)F_FLAGS * cap] = 0u;
+        f[(size_t)F_ENERGY * cap] = 1.0f;
+        f[(size_t)(F_LN + 0) * cap] = 0.0f; f[(size_t)(F_LN + 1) * cap] = 0.0f; f[(size_t)(F_LN + 2) * cap] = 0.0f;
+        ((uint32_t *)f)[(size_t)F_PHASE * cap] = PH_EXTEND;
+    }
+    // TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0; shade handles that case
+    uint32_t pos_q = wave_append(qcnt_next_ext, live);
+    if (live) q_ext_next[pos_q] = slot;
+}
+
+// ------------------------------------------------------------------------------------------ extend
+// The march loop of TraceRay (tracer.go:33-35, 226-256): closest hit on the segment [0, stepSize];
+// on a miss advance (straight) or RK4-step the geodesic (curved) and test the horizon.
+template <int STACK>
+__global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl, DevScene sc, RenderArgs ra,
+                                                             const uint32_t *queue, uint32_t n,
+                                                             unsigned long long *counters) {
+    __shared__ uint32_t smem[STACK * WAVE];
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    uint32_t nq = 0;
+    if (i < n) {
+        const uint32_t slot = queue[i], cap = pl.cap;
+        V3 o = mk(pl.ro[slot], pl.ro[cap + slot], pl.ro[2 * cap + slot]);
+        V3 d = mk(pl.rd[slot], pl.rd[cap + slot], pl.rd[2 * cap + slot]);
+        const bool curved = sc.has_bh != 0;
+        RayState st = {0, 0, 0, 0, 0, 0, 0, 0};
+        float vt0 = 1.0f;
+        if (curved) { st = get_initial_state(o, d, sc.bh); vt0 = st.vt; }          // tracer.go:28-31
+        int status = HS_MISS, prim = -1;
+        float t = 0.0f;
+        TravCounters tc;
+        for (int step = 0; step < ra.p.max_steps; ++step) {
+            ++nq;
+            closest_hit<WAVE, false>(bvh, smem + threadIdx.x, o.x, o.y, o.z, d.x, d.y, d.z, ra.p.step_size, prim, t, tc);
+            if (prim >= 0) { status = HS_HIT; break; }
+            if (!curved) {
+                o = add(o, scale(d, ra.p.step_size));                              // :226-228
+            } else {
+                st = rk4_step(st, ra.p.step_size, sc.bh.rs);                       // :231
+                V3 rel = mk(st.px, st.py, st.pz);
+                o = add(rel, mk(sc.bh.position));                                  // :238
+                d = normalize(mk(st.vx, st.vy, st.vz));                            // :241
+                if (dot(rel, rel) <= sc.bh.rs * sc.bh.rs) { status = HS_HORIZON; break; }   // :250-255
+            }
+        }
+        pl.ro[slot] = o.x; pl.ro[cap + slot] = o.y; pl.ro[2 * cap + slot] = o.z;
+        pl.rd[slot] = d.x; pl.rd[cap + slot] = d.y; pl.rd[2 * cap + slot] = d.z;
+        pl.hstatus[slot] = status; pl.hprim[slot] = prim; pl.ht[slot] = t;
+        pl.vt0[slot] = vt0; pl.vt1[slot] = st.vt;
+    }
+    for (int off = 32; off > 0; off >>= 1) nq += __shfl_xor(nq, off);
+    if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&counters[CNT_CLOSEST], (unsigned long long)nq);
+}
+
+// ------------------------------------------------------------------------------------------ connect
+template <int STACK>
+__global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool pl, uint32_t n,
+                                                              unsigned long long *counters) {
+    __shared__ uint32_t smem[STACK * WAVE];
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    if (i < n) {
+        const float4 a = pl.q_sray_a[i], b = pl.q_sray_b[i];
+        TravCounters tc;
+        bool occ = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, b.x, b.y, b.z, a.w, tc);
+        pl.sh_occ[__float_as_uint(b.w)] = occ ? 1 : 0;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t cnt = min((uint32_t)WAVE, n - blockIdx.x * WAVE);
+        atomicAdd(&counters[CNT_ANY], (unsigned long long)cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ shade
+
+struct Hit {            // a frame's hit, re-derived from the frame's stored ray + (t, prim)
+    V3 ro, rd, P, normal, A, B, C;
+    int prim;
+    uint32_t mat;
+};
+
+__device__ __forceinline__ V3 vert(const DevScene &sc, uint32_t vi) { return mk(sc.verts + 3 * (size_t)vi); }
+__device__ __forceinline__ V3 nrm(const DevScene &sc, size_t ci) { return mk(sc.normals + 3 * ci); }
+__device__ __forceinline__ bool is_emissive(const PtMaterial &m) { return m.ke[0] > 0.0f || m.ke[1] > 0.0f || m.ke[2] > 0.0f; }
+
+// States of the per-path machine inside one shade invocation.
+enum { ST_EXTENDED, ST_MATERIAL, ST_SHADOW_DONE, ST_GI_LOOP, ST_REFL_LOOP, ST_DIFFUSE_FINAL, ST_COMBINE, ST_RETURN };
+
+__global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, const uint32_t *list_a,
+                                                    uint32_t na, const uint32_t *list_b, uint32_t nb,
+                                                    uint32_t *q_ext_next, uint32_t *q_shpath_next,
+                                                    unsigned long long *counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < na + nb;
+    const uint32_t cap = pl.cap;
+    uint32_t slot = 0;
+    bool want_extend = false, want_shadow = false, finished = false;
+    uint32_t n_sray = 0;                       // shadow rays this path wants to enqueue
+    uint32_t diffuse_events = 0;
+    // shadow rays are staged in registers until the wave-wide queue reservation below
+    // (at most nshadow per path; written to the queue after the loop)
+    if (live) {
+        slot = i < na ? list_a[i] : list_b[i - na];
+        int depth = pl.depth[slot];
+        Rng rng; rng.key = pl.rng_key[slot]; rng.ctr = pl.rng_ctr[slot];
+        uint32_t trk_len = pl.trk_len[slot];
+#define FRF(dep, field) pl.fr[((size_t)(dep) * NF + (field)) * cap + slot]
+#define FRI(dep, field) (((int32_t *)pl.fr)[((size_t)(dep) * NF + (field)) * cap + slot])
+#define FRU(dep, field) (((uint32_t *)pl.fr)[((size_t)(dep) * NF + (field)) * cap + slot])
+#define FRV(dep, field) mk(FRF(dep, (field)), FRF(dep, (field) + 1), FRF(dep, (field) + 2))
+#define FRV_SET(dep, field, v) do { V3 v__ = (v); FRF(dep, (field)) = v__.x; FRF(dep, (field) + 1) = v__.y; FRF(dep, (field) + 2) = v__.z; } while (0)
+#define TRK(k) pl.trk[(size_t)(k) * cap + slot]
+        auto trk_current = [&]() -> float { return trk_len == 0 ? 1.0f : TRK(trk_len - 1); };
+        auto trk_previous = [&]() -> float { return trk_len < 2 ? 1.0f : TRK(trk_len - 2); };
+
+        // (re)derive the hit of frame `dep` from what the frame stores
+        auto load_hit = [&](int dep, Hit &h) {
+            h.ro = FRV(dep, F_RO); h.rd = FRV(dep, F_RD);
+            h.prim = FRI(dep, F_PRIM);
+            float t = FRF(dep, F_T);
+            h.P = add(h.ro, scale(h.rd, t));                                        // tracer.go:37
+            const uint32_t *ix = sc.tri_idx + 3 * (size_t)h.prim;
+            h.A = vert(sc, ix[0]); h.B = vert(sc, ix[1]); h.C = vert(sc, ix[2]);
+            V3 n = normalize(interpolate_normal(h.P, h.A, h.B, h.C, nrm(sc, 3 * (size_t)h.prim),
+                                                nrm(sc, 3 * (size_t)h.prim + 1), nrm(sc, 3 * (size_t)h.prim + 2)));   // :38-46
+            if (FRU(dep, F_FLAGS) & FL_FLIPPED) n = scale(n, -1.0f);                // :53
+            h.normal = n;
+            h.mat = sc.tri_mat[h.prim];
+        };
+        // push a child TraceRay invocation and request its extend
+        auto push_child = [&](int dep, int bounces, int bindex, V3 lastN, bool specular, float energy, V3 o, V3 d) {
+            FRI(dep + 1, F_BOUNCES) = bounces; FRI(dep + 1, F_BINDEX) = bindex;
+            FRU(dep + 1, F_FLAGS) = specular ? FL_SPECULAR : 0u;
+            FRF(dep + 1, F_ENERGY) = energy; FRV_SET(dep + 1, F_LN, lastN);
+            FRU(dep + 1, F_PHASE) = PH_EXTEND;
+            pl.ro[slot] = o.x; pl.ro[cap + slot] = o.y; pl.ro[2 * cap + slot] = o.z;
+            pl.rd[slot] = d.x; pl.rd[cap + slot] = d.y; pl.rd[2 * cap + slot] = d.z;
+        };
+
+        int state;
+        V3 ret = mk(0, 0, 0);
+        Hit h;
+        bool have_hit = false;
+        // entry: what was the top frame waiting for?
+        {
+            uint32_t ph = FRU(depth, F_PHASE);
+            if (ph == PH_EXTEND) state = ST_EXTENDED;
+            else { load_hit(depth, h); have_hit = true; state = ST_SHADOW_DONE; }   // PH_SHADOW_WAIT
+        }
+        for (;;) {
+            if (state == ST_EXTENDED) {
+                // TraceRay entry test (tracer.go:16) for the primary ray; children are tested before being pushed
+                if (FRI(depth, F_BOUNCES) < 0 || FRF(depth, F_ENERGY) < (float)1e-2) { ret = mk(0, 0, 0); state = ST_RETURN; continue; }
+                const int hs = pl.hstatus[slot];
+                V3 o = mk(pl.ro[slot], pl.ro[cap + slot], pl.ro[2 * cap + slot]);
+                V3 d = mk(pl.rd[slot], pl.rd[cap + slot], pl.rd[2 * cap + slot]);
+                if (hs == HS_HORIZON) { ret = mk(0, 0, 0); state = ST_RETURN; continue; }           // :253-255
+                if (hs == HS_MISS) {                                                                // :260-263
+                    ret = sc.sky.kind == PTMI_SKY_NONE ? mk(0, 0, 0) : sky_sample(sc.sky, sc.sky_img, d);
+                    state = ST_RETURN; continue;
+                }
+                FRV_SET(depth, F_RO, o); FRV_SET(depth, F_RD, d);
+                FRF(depth, F_T) = pl.ht[slot]; FRI(depth, F_PRIM) = pl.hprim[slot];
+                FRU(depth, F_FLAGS) &= ~(uint32_t)FL_FLIPPED;
+                load_hit(depth, h); have_hit = true;
+                const PtMaterial &m = sc.mats[h.mat];
+                // doppler / gravitational factors and the disk colour depend only on this hit (:93-113)
+                float dg = 1.0f;
+                V3 diff0 = mk(0, 0, 0);
+                if ((m.flags & PTMI_MAT_ACCRETION) && sc.has_bh) {
+                    V3 rel = sub(h.P, mk(sc.bh.position));
+                    V3 tang = normalize(cross(mk(0, 1, 0), rel));
+                    V3 vel = scale(tang, (float)0.9999);
+                    float vpar = dot(scale(h.rd, -1.0f), vel);
+                    float doppler = sqrtf((1.0f + vpar) / (1.0f - vpar));
+                    float grav = pl.vt0[slot] / pl.vt1[slot];
+                    dg = doppler * grav;
+                    if (sc.bh.has_disk) diff0 = disk_color(sc.bh, h.P);
+                }
+                FRF(depth, F_DG) = dg; FRV_SET(depth, F_DIFF, diff0);
+                FRV_SET(depth, F_REFR, mk(0, 0, 0));
+                if (m.flags & PTMI_MAT_GLASS) {                                                     // :49-91
+                    float ri = m.ni;
+                    bool goingOut = false;
+                    if (dot(h.normal, h.rd) > 0.0f) {
+                        h.normal = scale(h.normal, -1.0f); goingOut = true; ri = trk_previous();
+                        FRU(depth, F_FLAGS) |= FL_FLIPPED;
+                    }
+                    bool tir;
+                    V3 rdir = get_refracted_ray(h.rd, h.normal, trk_current(), ri, tir);
+                    V3 rorg = add(h.P, scale(rdir, (float)0.001));
+                    const int bounces = FRI(depth, F_BOUNCES), bindex = FRI(depth, F_BINDEX);
+                    const float energy = FRF(depth, F_ENERGY);
+                    int cbi = bindex + 1;
+                    if (!tir) {
+                        if (goingOut) { if (trk_len > 0) trk_len--; } else if ((int)trk_len < pl.ntrk) { TRK(trk_len) = ri; trk_len++; }
+                        cbi = bindex;
+                    }
+                    const float ce = energy * (float)0.95;
+                    if (!(ce < (float)1e-2 || bounces - 1 < 0)) {
+                        FRU(depth, F_PHASE) = PH_REFR_WAIT;
+                        push_child(depth, bounces - 1, cbi, FRV(depth, F_LN), (FRU(depth, F_FLAGS) & FL_SPECULAR) != 0, ce, rorg, rdir);
+                        depth++; want_extend = true; break;
+                    }
+                    // the child returns Vec3{} at its entry test: refraction = {} * energy
+                    FRV_SET(depth, F_REFR, scale(mk(0, 0, 0), energy));
+                }
+                state = ST_MATERIAL; continue;
+            }
+            if (state == ST_MATERIAL) {
+                if (!have_hit) { load_hit(depth, h); have_hit = true; }
+                const PtMaterial &m = sc.mats[h.mat];
+                const float reflectivity = (m.ks[0] + m.ks[1] + m.ks[2]) / 3.0f;                    // :116
+                bool take_reflective;
+                if (reflectivity < (float)0.1) take_reflective = false;
+                else if (reflectivity < (float)0.9) take_reflective = rng_f32(rng) < reflectivity;  // :163
+                else take_reflective = true;
+                FRV_SET(depth, F_SUM, mk(0, 0, 0)); FRI(depth, F_S) = 0;
+                if (take_reflective) { state = ST_REFL_LOOP; continue; }
+                const int bindex = FRI(depth, F_BINDEX);
+                if (bindex > 0 && is_emissive(m)) {                                                 // :461-465
+                    V3 dc = mk(m.ke);
+                    if (!(FRU(depth, F_FLAGS) & FL_SPECULAR)) {                                     // :143-158
+                        float pdf_brdf = dot(h.rd, FRV(depth, F_LN)) / PT_PI32;
+                        float area = triangle_area(h.A, h.B, h.C);
+                        float pdf_area = 1.0f / ((float)sc.nemissive * area);
+                        float cosLight = gomaxf(0.0f, dot(h.rd, h.normal));
+                        float distance = length(sub(h.P, h.ro));
+                        float pdf_sa = pdf_area * distance * distance / cosLight;
+                        dc = scale(dc, mis_weight(pdf_brdf, pdf_sa));
+                    }
+                    FRV_SET(depth, F_DIFF, dc);
+                    state = ST_COMBINE; continue;
+                }
+                // direct lighting of HandleDiffuseMaterial (:523-618): draw in the reference's order, stage the
+                // shadow rays, resume in ST_SHADOW_DONE once `connect` has answered them
+                const V3 albedo = mk(m.kd);
+                const V3 rayOrigin = add(h.P, scale(h.normal, (float)0.001));                       // :528
+                uint32_t need = 0;
+                auto stage = [&](int k, V3 o, V3 d, float range, V3 contrib) {
+                    need |= 1u << k;
+                    pl.sh_contrib[(size_t)(3 * k) * cap + slot] = contrib.x;
+                    pl.sh_contrib[(size_t)(3 * k + 1) * cap + slot] = contrib.y;
+                    pl.sh_contrib[(size_t)(3 * k + 2) * cap + slot] = contrib.z;
+                    // ray parked in the path's own shadow slots; copied to the queue after the reservation
+                    pl.q_sray_a[(size_t)cap * pl.nshadow + (size_t)k * cap + slot] = make_float4(o.x, o.y, o.z, range);
+                    pl.q_sray_b[(size_t)cap * pl.nshadow + (size_t)k * cap + slot] = make_float4(d.x, d.y, d.z, 0.0f);
+                    n_sray++;
+                };
+                if (sc.sky.kind != PTMI_SKY_NONE) {                                                 // :531-542
+                    V3 t1, t2; tangent_frame(h.normal, t1, t2);
+                    V3 rn = cosine_sample2(rng, h.normal, t1, t2);
+                    stage(0, rayOrigin, rn, 100000.0f, cmul(sky_sample(sc.sky, sc.sky_img, rn), albedo));
+                }
+                for (uint32_t li = 0; li < sc.nlights; ++li) {                                      // :545-560
+                    const PtLight &L = sc.lights[li];
+                    if (L.kind == PTMI_LIGHT_SUN) {                                                 // lights.go:18-28
+                        V3 ld = mk(L.vec);
+                        float ndotr = dot(ld, h.normal);
+                        if (!(ndotr < 0.0f)) stage(1 + li, rayOrigin, ld, ra.p.step_size, scale(mk(L.color), ndotr * L.intensity));
+                    } else {                                                                        // lights.go:38-54
+                        V3 ld = normalize(sub(mk(L.vec), rayOrigin));
+                        V3 toLight = sub(mk(L.vec), rayOrigin);
+                        float distance = length(toLight);
+                        toLight = normalize(toLight);
+                        float ndotl = dot(h.normal, toLight);
+                        if (!(ndotl <= 0.0f)) {
+                            float att = 1.0f / (distance * distance);
+                            stage(1 + li, rayOrigin, ld, distance, scale(mk(L.color), ndotl * L.intensity * att));
+                        }
+                    }
+                }
+                if (sc.nemissive > 0) {                                                             // :562-618
+                    V3 eo = add(h.P, scale(h.normal, (float)0.01));
+                    uint32_t choice = rng_intn(rng, sc.nemissive);
+                    uint32_t et = sc.emissive[choice];
+                    const uint32_t *ix = sc.tri_idx + 3 * (size_t)et;
+                    V3 p0 = vert(sc, ix[0]), p1 = vert(sc, ix[1]), p2 = vert(sc, ix[2]);
+                    V3 lightPoint = sample_triangle_point(rng, p0, p1, p2);
+                    V3 lsn = interpolate_normal(lightPoint, p0, p1, p2, nrm(sc, 3 * (size_t)et), nrm(sc, 3 * (size_t)et + 1), nrm(sc, 3 * (size_t)et + 2));
+                    V3 toLight = sub(lightPoint, eo);
+                    float distance = length(toLight);
+                    toLight = normalize(toLight);
+                    float ndotl = dot(toLight, h.normal);
+                    if (!(ndotl <= 0.0f)) {
+                        V3 ec = mk(0, 0, 0);
+                        float sndorl = -dot(toLight, lsn);
+                        if (!(sndorl <= 0.0f)) {
+                            float geometryTerm = ndotl * sndorl / (distance * distance);
+                            float pdf = triangle_area(p0, p1, p2);
+                            pdf = 1.0f / (pdf * (float)sc.nemissive);
+                            float pdf_brdf = dot(h.normal, toLight) / PT_PI32;
+                            float pdf_sa = pdf * (distance * distance) / sndorl;
+                            float weight = mis_weight(pdf_sa, pdf_brdf);
+                            V3 le = mk(sc.mats[sc.tri_mat[et]].ke);
+                            V3 brdf = scale(albedo, (float)(1.0 / 3.14159265358979323846));
+                            ec = scale(cmul(le, brdf), geometryTerm * weight / pdf);
+                        }
+                        stage(1 + (int)sc.nlights, eo, toLight, distance - (float)0.01, ec);
+                    }
+                }
+                FRU(depth, F_NEED) = need;
+                if (need) { FRU(depth, F_PHASE) = PH_SHADOW_WAIT; want_shadow = true; break; }
+                state = ST_SHADOW_DONE; continue;
+            }
+            if (state == ST_SHADOW_DONE) {
+                if (!have_hit) { load_hit(depth, h); have_hit = true; }
+                const PtMaterial &m = sc.mats[h.mat];
+                const V3 albedo = mk(m.kd);
+                const uint32_t need = FRU(depth, F_NEED);
+                auto lit = [&](int k) -> bool { return (need >> k & 1u) && pl.sh_occ[(size_t)k * cap + slot] == 0; };
+                auto contrib = [&](int k) -> V3 {
+                    return mk(pl.sh_contrib[(size_t)(3 * k) * cap + slot], pl.sh_contrib[(size_t)(3 * k + 1) * cap + slot],
+                              pl.sh_contrib[(size_t)(3 * k + 2) * cap + slot]);
+                };
+                V3 direct = mk(0, 0, 0);
+                if (sc.sky.kind != PTMI_SKY_NONE && lit(0)) direct = add(direct, contrib(0));       // :538-540
+                for (uint32_t li = 0; li < sc.nlights; ++li) {                                      // :557-559
+                    V3 c = lit(1 + li) ? contrib(1 + li) : mk(0, 0, 0);
+                    direct = add(direct, cmul(albedo, c));
+                }
+                if (sc.nemissive > 0) {                                                             // :617
+                    V3 c = lit(1 + (int)sc.nlights) ? contrib(1 + (int)sc.nlights) : mk(0, 0, 0);
+                    direct = add(direct, c);
+                }
+                FRV_SET(depth, F_DIRECT, direct);
+                if (FRI(depth, F_BOUNCES) > 0) { state = ST_GI_LOOP; continue; }                    // :622
+                state = ST_DIFFUSE_FINAL; continue;
+            }
+            if (state == ST_GI_LOOP) {                                                              // :636-647
+                if (!have_hit) { load_hit(depth, h); have_hit = true; }
+                const int s = FRI(depth, F_S);
+                if (s < ra.p.scatter_rays) {
+                    V3 t1, t2; tangent_frame(h.normal, t1, t2);
+                    V3 dir = cosine_sample2(rng, h.normal, t1, t2);
+                    // bounces > 0 and the energy is this frame's own (already >= 1e-2): the child always runs
+                    FRU(depth, F_PHASE) = PH_GI_WAIT;
+                    push_child(depth, FRI(depth, F_BOUNCES) - 1, FRI(depth, F_BINDEX) + 1, h.normal, false,
+                               FRF(depth, F_ENERGY), add(h.P, scale(h.normal, (float)0.001)), dir);
+                    depth++; want_extend = true; break;
+                }
+                FRV_SET(depth, F_SUM, scale(FRV(depth, F_SUM), 1.0f / (float)ra.p.scatter_rays));
+                state = ST_DIFFUSE_FINAL; continue;
+            }
+            if (state == ST_DIFFUSE_FINAL) {                                                        // :658-667
+                if (!have_hit) { load_hit(depth, h); have_hit = true; }
+                const PtMaterial &m = sc.mats[h.mat];
+                V3 indirect = FRI(depth, F_BOUNCES) > 0 ? FRV(depth, F_SUM) : mk(0, 0, 0);
+                V3 fin = FRV(depth, F_DIRECT);
+                fin = add(fin, scale(mk(m.kd), ra.p.ambient));
+                fin = add(fin, scale(indirect, 1.0f));
+                if (FRI(depth, F_BINDEX) == 0 && is_emissive(m)) fin = add(fin, mk(m.ke));
+                diffuse_events++;
+                FRV_SET(depth, F_DIFF, fin);
+                FRV_SET(depth, F_SUM, mk(0, 0, 0));          // reflective component stays zero on this branch
+                state = ST_COMBINE; continue;
+            }
+            if (state == ST_REFL_LOOP) {                                                            // :670-722
+                if (!have_hit) { load_hit(depth, h); have_hit = true; }
+                const PtMaterial &m = sc.mats[h.mat];
+                const int bounces = FRI(depth, F_BOUNCES);
+                bool pushed = false;
+                while (FRI(depth, F_S) < ra.p.scatter_rays) {
+                    float roughness = 1.0f / (1.0f + m.ns / 100.0f);
+                    float dp = dot(h.rd, h.normal);
+                    V3 reflDir = normalize(sub(h.rd, scale(h.normal, 2.0f * dp)));
+                    V3 sd = sample_glossy(rng, reflDir, roughness);
+                    if (bounces - 1 < 0) {          // the child returns Vec3{} at its entry test (:16)
+                        FRV_SET(depth, F_SUM, add(FRV(depth, F_SUM), mk(0, 0, 0)));
+                        FRI(depth, F_S) = FRI(depth, F_S) + 1;
+                        continue;
+                    }
+                    FRU(depth, F_PHASE) = PH_REFL_WAIT;
+                    push_child(depth, bounces - 1, FRI(depth, F_BINDEX) + 1, h.normal, true, FRF(depth, F_ENERGY),
+                               add(h.P, scale(h.normal, (float)0.001)), sd);
+                    depth++; want_extend = true; pushed = true; break;
+                }
+                if (pushed) break;
+                V3 sum = scale(FRV(depth, F_SUM), 1.0f / (float)ra.p.scatter_rays);
+                sum = cmul(sum, mk(m.ks));
+                FRV_SET(depth, F_SUM, add(sum, FRV(depth, F_REFR)));                                // :165, :211
+                state = ST_COMBINE; continue;
+            }
+            if (state == ST_COMBINE) {                                                              // :218-223
+                V3 refr = FRV(depth, F_REFR);
+                float diffuseScale = 1.0f;
+                if (length(refr) > 0.0f) diffuseScale = (float)0.1;
+                V3 fin = add(add(add(scale(FRV(depth, F_DIFF), diffuseScale), mk(0, 0, 0)), FRV(depth, F_SUM)), refr);
+                ret = scale(fin, FRF(depth, F_DG));
+                state = ST_RETURN; continue;
+            }
+            // ST_RETURN: hand `ret` to the caller frame
+            if (depth == 0) {
+                float *o = pl.out + 3 * (size_t)pl.sid[slot];
+                o[0] = ret.x; o[1] = ret.y; o[2] = ret.z;
+                finished = true; break;
+            }
+            depth--; have_hit = false;
+            const uint32_t ph = FRU(depth, F_PHASE);
+            if (ph == PH_REFR_WAIT) {                                                               // :78, :89
+                FRV_SET(depth, F_REFR, scale(ret, FRF(depth, F_ENERGY)));
+                state = ST_MATERIAL;
+            } else if (ph == PH_GI_WAIT) {                                                          // :640-645
+                load_hit(depth, h); have_hit = true;
+                V3 c = cmul(ret, mk(sc.mats[h.mat].kd));
+                FRV_SET(depth, F_SUM, add(FRV(depth, F_SUM), c));
+                FRI(depth, F_S) = FRI(depth, F_S) + 1;
+                state = ST_GI_LOOP;
+            } else {                                                                                // PH_REFL_WAIT :715
+                FRV_SET(depth, F_SUM, add(FRV(depth, F_SUM), ret));
+                FRI(depth, F_S) = FRI(depth, F_S) + 1;
+                state = ST_REFL_LOOP;
+            }
+        }
+        pl.depth[slot] = depth;
+        pl.rng_ctr[slot] = rng.ctr;
+        pl.trk_len[slot] = trk_len;
+#undef FRF
+#undef FRI
+#undef FRU
+#undef FRV
+#undef FRV_SET
+#undef TRK
+    }
+    // ---- queue compaction: one atomic per wave and queue ----
+    uint32_t pe = wave_append(&pl.qcnt[Q_WORDS + Q_EXT], want_extend);
+    if (want_extend) q_ext_next[pe] = slot;
+    uint32_t ps = wave_append(&pl.qcnt[Q_WORDS + Q_SHADOW_PATHS], want_shadow);
+    if (want_shadow) q_shpath_next[ps] = slot;
+    uint32_t pf = wave_append(&pl.qcnt[Q_FREE], finished);
+    if (finished) pl.q_free[pf] = slot;
+    // shadow rays: reserve n_sray consecutive entries per lane with a wave-level exclusive scan
+    {
+        uint32_t incl = n_sray;
+        const int lane = threadIdx.x & 63;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        uint32_t total = __shfl(incl, 63);
+        unsigned long long base = 0;
+        if (lane == 63 && total) base = atomicAdd(&pl.qcnt[Q_SHADOW_RAYS], (unsigned long long)total);
+        base = __shfl((long long)base, 63);
+        if (n_sray) {
+            uint32_t pos = (uint32_t)base + (incl - n_sray);
+            const uint32_t need = ((uint32_t *)pl.fr)[((size_t)pl.depth[slot] * NF + F_NEED) * cap + slot];
+            for (int k = 0; k < pl.nshadow; ++k) {
+                if (!(need >> k & 1u)) continue;
+                const size_t park = (size_t)cap * pl.nshadow + (size_t)k * cap + slot;
+                float4 a = pl.q_sray_a[park], b = pl.q_sray_b[park];
+                b.w = __uint_as_float((uint32_t)((size_t)k * cap + slot));
+                pl.q_sray_a[pos] = a; pl.q_sray_b[pos] = b;
+                ++pos;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) diffuse_events += __shfl_xor(diffuse_events, off);
+    uint32_t fin = finished ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) fin += __shfl_xor(fin, off);
+    if ((threadIdx.x & 63) == 0) {
+        if (diffuse_events) atomicAdd(&counters[CNT_DIFFUSE], (unsigned long long)diffuse_events);
+        if (fin) atomicAdd(&counters[CNT_SAMPLES], (unsigned long long)fin);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ accumulate
+// Pixel.AddSample's running sums (renderer.go:29, 59-61): R += c.X ... in sample order.
+__global__ __launch_bounds__(256) void accumulate_kernel(const float *out, uint32_t npix, uint32_t spp, float *accum,
+                                                         uint32_t *counts) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float r = accum[3 * (size_t)p], g = accum[3 * (size_t)p + 1], b = accum[3 * (size_t)p + 2];
+    const float *o = out + 3 * (size_t)p * spp;
+    for (uint32_t s = 0; s < spp; ++s) { r += o[3 * s]; g += o[3 * s + 1]; b += o[3 * s + 2]; }
+    accum[3 * (size_t)p] = r; accum[3 * (size_t)p + 1] = g; accum[3 * (size_t)p + 2] = b;
+    counts[p] += spp;
+}
+
+}  // namespace
+
+// ============================================================================================ host side
+
+struct RenderState {
+    // scene (device)
+    bool have_scene = false;
+    float *d_verts = nullptr; uint32_t *d_tri_idx = nullptr; float *d_normals = nullptr; uint32_t *d_tri_mat = nullptr;
+    PtMaterial *d_mats = nullptr; uint32_t *d_emissive = nullptr; uint32_t nemissive = 0;
+    PtLight *d_lights = nullptr; uint32_t nlights = 0;
+    PtSky sky{}; uint16_t *d_sky_img = nullptr;
+    PtBlackHole bh{}; int has_bh = 0;
+    // pool (device), sized for (cap, bounces, nlights)
+    char *pool_mem = nullptr; size_t pool_bytes = 0;
+    uint32_t pool_cap = 0; int pool_bounces = -2, pool_nlights = -1;
+    Pool pool{};
+    float *d_out = nullptr; size_t out_bytes = 0;
+    float *d_accum = nullptr; uint32_t *d_counts = nullptr; size_t accum_pix = 0;
+};
 
 namespace ptmi {
-void free_scene(ptmi_ctx *) {}
+void free_scene(ptmi_ctx *ctx) {
+    RenderState *rs = ctx->render;
+    if (!rs) return;
+    void *ptrs[] = {rs->d_verts, rs->d_tri_idx, rs->d_normals, rs->d_tri_mat, rs->d_mats, rs->d_emissive, rs->d_lights,
+                    rs->d_sky_img, rs->pool_mem, rs->d_out, rs->d_accum, rs->d_counts};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete rs;
+    ctx->render = nullptr;
+}
 }  // namespace ptmi
+
+template <typename T>
+static int upload(ptmi_ctx *ctx, T *&dst, const T *src, size_t n) {
+    if (dst) { (void)hipFree(dst); dst = nullptr; }
+    PTMI_HIP(ctx, hipMalloc((void **)&dst, std::max<size_t>(n, 1) * sizeof(T)));
+    if (n) PTMI_HIP(ctx, hipMemcpy(dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_upload_scene(ptmi_ctx *ctx, const PtMaterial *materials, uint64_t nmaterials,
+                                 const uint32_t *tri_material, const float *corner_normals, const PtLight *lights,
+                                 uint64_t nlights, const PtSky *sky, const uint16_t *sky_image,
+                                 const PtBlackHole *blackhole) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_upload_scene: ctx is null");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_upload_scene: build or upload a BVH first");
+    const uint64_t ntris = ctx->tri_idx.size() / 3;
+    if (!materials || !nmaterials || (!tri_material && ntris) || (!corner_normals && ntris) || !sky || (!lights && nlights))
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: null array");
+    if (nlights > 29) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: at most 29 lights");
+    for (uint64_t t = 0; t < ntris; ++t)
+        if (tri_material[t] >= nmaterials) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: material index out of range");
+    if (sky->kind < 0 || sky->kind > 3) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: bad sky kind");
+    if (sky->kind == PTMI_SKY_IMAGE && (!sky_image || sky->image_width < 1 || sky->image_height < 1))
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: image sky without image");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->render) ctx->render = new RenderState();
+    RenderState *rs = ctx->render;
+    rs->have_scene = false;
+    int rc;
+    if ((rc = upload(ctx, rs->d_verts, ctx->verts.data(), ctx->verts.size()))) return rc;
+    if ((rc = upload(ctx, rs->d_tri_idx, ctx->tri_idx.data(), ctx->tri_idx.size()))) return rc;
+    if ((rc = upload(ctx, rs->d_normals, corner_normals, (size_t)ntris * 9))) return rc;
+    if ((rc = upload(ctx, rs->d_tri_mat, tri_material, (size_t)ntris))) return rc;
+    if ((rc = upload(ctx, rs->d_mats, materials, (size_t)nmaterials))) return rc;
+    if ((rc = upload(ctx, rs->d_lights, lights, (size_t)nlights))) return rc;
+    std::vector<uint32_t> em;                                   // renderer.go:311-321
+    for (uint64_t t = 0; t < ntris; ++t) {
+        const PtMaterial &m = materials[tri_material[t]];
+        if (m.ke[0] > 0.0f || m.ke[1] > 0.0f || m.ke[2] > 0.0f) em.push_back((uint32_t)t);
+    }
+    if ((rc = upload(ctx, rs->d_emissive, em.data(), em.size()))) return rc;
+    rs->nemissive = (uint32_t)em.size();
+    rs->nlights = (uint32_t)nlights;
+    rs->sky = *sky;
+    if (sky->kind == PTMI_SKY_IMAGE) {
+        if ((rc = upload(ctx, rs->d_sky_img, sky_image, (size_t)sky->image_width * sky->image_height * 3))) return rc;
+    }
+    rs->has_bh = blackhole ? 1 : 0;
+    if (blackhole) rs->bh = *blackhole; else std::memset(&rs->bh, 0, sizeof rs->bh);
+    rs->have_scene = true;
+    return PTMI_OK;
+}
+
+static size_t carve(size_t &off, size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+}
+
+static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces) {
+    RenderState *rs = ctx->render;
+    if (rs->pool_mem && rs->pool_cap == cap && rs->pool_bounces == bounces && rs->pool_nlights == (int)rs->nlights)
+        return PTMI_OK;
+    if (rs->pool_mem) { (void)hipFree(rs->pool_mem); rs->pool_mem = nullptr; }
+    Pool p{};
+    p.cap = cap;
+    p.nframes = bounces + 1; p.nshadow = (int)rs->nlights + 2;
+    // every TraceRay invocation can push one index and the sibling subtrees share the tracker, so its history is
+    // bounded by the number of invocations, 2^(bounces+1)-1 (capped at 64 entries, like the oracle)
+    p.ntrk = bounces + 1 >= 6 ? 64 : (1 << (bounces + 1)) + 1;
+    size_t off = 0;
+    const size_t c = cap;
+    size_t o_sid = carve(off, 4 * c), o_key = carve(off, 4 * c), o_ctr = carve(off, 4 * c), o_depth = carve(off, 4 * c);
+    size_t o_tl = carve(off, 4 * c), o_trk = carve(off, 4 * c * p.ntrk);
+    size_t o_ro = carve(off, 12 * c), o_rd = carve(off, 12 * c);
+    size_t o_hs = carve(off, 4 * c), o_hp = carve(off, 4 * c), o_ht = carve(off, 4 * c), o_v0 = carve(off, 4 * c), o_v1 = carve(off, 4 * c);
+    size_t o_fr = carve(off, 4 * c * (size_t)p.nframes * NF);
+    size_t o_shc = carve(off, 12 * c * p.nshadow), o_sho = carve(off, c * p.nshadow);
+    size_t o_qe0 = carve(off, 4 * c), o_qe1 = carve(off, 4 * c), o_qs0 = carve(off, 4 * c), o_qs1 = carve(off, 4 * c);
+    // shadow-ray queue: first cap*nshadow entries are the compacted queue, the next cap*nshadow the per-path parking area
+    size_t o_ra = carve(off, 16 * c * p.nshadow * 2), o_rb = carve(off, 16 * c * p.nshadow * 2);
+    size_t o_free = carve(off, 4 * c), o_cnt = carve(off, 8 * 2 * Q_WORDS);
+    PTMI_HIP(ctx, hipMalloc((void **)&rs->pool_mem, off));
+    rs->pool_bytes = off;
+    char *b = rs->pool_mem;
+    p.sid = (uint32_t *)(b + o_sid); p.rng_key = (uint32_t *)(b + o_key); p.rng_ctr = (uint32_t *)(b + o_ctr);
+    p.depth = (int32_t *)(b + o_depth); p.trk_len = (uint32_t *)(b + o_tl); p.trk = (float *)(b + o_trk);
+    p.ro = (float *)(b + o_ro); p.rd = (float *)(b + o_rd);
+    p.hstatus = (int32_t *)(b + o_hs); p.hprim = (int32_t *)(b + o_hp); p.ht = (float *)(b + o_ht);
+    p.vt0 = (float *)(b + o_v0); p.vt1 = (float *)(b + o_v1);
+    p.fr = (float *)(b + o_fr); p.sh_contrib = (float *)(b + o_shc); p.sh_occ = (uint8_t *)(b + o_sho);
+    p.q_ext[0] = (uint32_t *)(b + o_qe0); p.q_ext[1] = (uint32_t *)(b + o_qe1);
+    p.q_shpath[0] = (uint32_t *)(b + o_qs0); p.q_shpath[1] = (uint32_t *)(b + o_qs1);
+    p.q_sray_a = (float4 *)(b + o_ra); p.q_sray_b = (float4 *)(b + o_rb);
+    p.q_free = (uint32_t *)(b + o_free); p.qcnt = (unsigned long long *)(b + o_cnt);
+    rs->pool = p;
+    rs->pool_cap = cap; rs->pool_bounces = bounces; rs->pool_nlights = (int)rs->nlights;
+    return PTMI_OK;
+}
+
+template <int STACK>
+static void launch_render_extend(ptmi_ctx *ctx, const DevScene &sc, const RenderArgs &ra, const uint32_t *q, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL((render_extend_kernel<STACK>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
+                       ctx->render->pool, sc, ra, q, n, ctx->d_counters);
+}
+template <int STACK>
+static void launch_render_connect(ptmi_ctx *ctx, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
+                       ctx->render->pool, n, ctx->d_counters);
+}
+
+// Renders samples [spp_begin, spp_begin+spp_count) of the rectangle into d_out chunks and accumulates them
+// into d_accum / d_counts (device pointers); or, when out_samples_host != nullptr, copies raw samples out.
+static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, int x0, int y0, int w, int h,
+                       uint32_t spp_begin, uint32_t spp_count, float *d_accum, uint32_t *d_counts, float *out_samples_host,
+                       hipStream_t s) {
+    RenderState *rs = ctx->render;
+    if (!rs || !rs->have_scene) return set_err(ctx, PTMI_ERR_NO_SCENE, "ptmi_render: no scene uploaded");
+    if (!cam || !prm) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: null camera / params");
+    if (w <= 0 || h <= 0 || prm->width <= 0 || prm->height <= 0 || x0 < 0 || y0 < 0 || x0 + w > prm->width || y0 + h > prm->height)
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: rectangle outside the image");
+    if (prm->bounces > 30 || prm->scatter_rays < 1 || prm->max_steps < 0)
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: need bounces <= 30, scatter_rays >= 1, max_steps >= 0");
+    if (spp_count == 0) return PTMI_OK;
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t npix = (uint64_t)w * h;
+    if (npix * 3 >= 0xFFFFFFFFull) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: rectangle too large");
+    const int bounces = std::max(prm->bounces, 0);
+
+    // samples per pixel per batch: bound the per-sample output buffer (<= ~3 GiB, < 2^32/3 samples)
+    uint32_t spp_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp_count, (256ull << 20) / npix));
+    const uint64_t max_total = npix * spp_chunk;
+    uint32_t cap = (uint32_t)std::min<uint64_t>(max_total, 1u << 21);
+    cap = (cap + 255) / 256 * 256;
+    int rc = ensure_pool(ctx, cap, bounces);
+    if (rc) return rc;
+    if (rs->out_bytes < max_total * 12) {
+        if (rs->d_out) { (void)hipFree(rs->d_out); rs->d_out = nullptr; }
+        PTMI_HIP(ctx, hipMalloc((void **)&rs->d_out, max_total * 12));
+        rs->out_bytes = max_total * 12;
+    }
+    Pool &pl = rs->pool;
+    pl.out = rs->d_out;
+
+    DevScene sc{};
+    sc.verts = rs->d_verts; sc.tri_idx = rs->d_tri_idx; sc.normals = rs->d_normals; sc.tri_mat = rs->d_tri_mat;
+    sc.mats = rs->d_mats; sc.emissive = rs->d_emissive; sc.nemissive = rs->nemissive;
+    sc.lights = rs->d_lights; sc.nlights = rs->nlights; sc.sky = rs->sky; sc.sky_img = rs->d_sky_img;
+    sc.bh = rs->bh; sc.has_bh = rs->has_bh;
+
+    const int dep = ctx->max_depth;
+    for (uint32_t done = 0; done < spp_count; done += spp_chunk) {
+        const uint32_t chunk = std::min(spp_chunk, spp_count - done);
+        RenderArgs ra{};
+        ra.cam = *cam; ra.p = *prm; ra.x0 = x0; ra.y0 = y0; ra.w = w; ra.h = h;
+        ra.spp_begin = spp_begin + done; ra.spp_chunk = chunk; ra.total = npix * chunk;
+
+        // counters: [0..Q_WORDS) = current (Q_FREE lives here), [Q_WORDS..2*Q_WORDS) = "next" queues filled by shade/generate
+        PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, 2 * Q_WORDS * sizeof(unsigned long long), s));
+        uint64_t next_sample = 0;
+        int cur = 0;
+        // initial fill
+        uint32_t n0 = (uint32_t)std::min<uint64_t>(cap, ra.total);
+        hipLaunchKernelGGL(generate_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, pl, ra, (const uint32_t *)nullptr, n0,
+                           next_sample, &pl.qcnt[Q_WORDS + Q_EXT], pl.q_ext[cur]);
+        next_sample += n0;
+        unsigned long long hc[2 * Q_WORDS];
+        PTMI_HIP(ctx, hipMemcpyAsync(hc, pl.qcnt, sizeof hc, hipMemcpyDeviceToHost, s));
+        PTMI_HIP(ctx, hipStreamSynchronize(s));
+        uint32_t n_ext = (uint32_t)hc[Q_WORDS + Q_EXT], n_shp = 0, n_srays = 0;
+        uint64_t guard = 0;
+        while (n_ext + n_shp > 0) {
+            if (++guard > 100000000ull) return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: wavefront loop did not terminate");
+            PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, 2 * Q_WORDS * sizeof(unsigned long long), s));
+            if (n_ext) {
+                if (dep <= 16) launch_render_extend<16>(ctx, sc, ra, pl.q_ext[cur], n_ext, s);
+                else if (dep <= 24) launch_render_extend<24>(ctx, sc, ra, pl.q_ext[cur], n_ext, s);
+                else if (dep <= 32) launch_render_extend<32>(ctx, sc, ra, pl.q_ext[cur], n_ext, s);
+                else if (dep <= 48) launch_render_extend<48>(ctx, sc, ra, pl.q_ext[cur], n_ext, s);
+                else launch_render_extend<64>(ctx, sc, ra, pl.q_ext[cur], n_ext, s);
+            }
+            if (n_srays) {
+                if (dep <= 16) launch_render_connect<16>(ctx, n_srays, s);
+                else if (dep <= 24) launch_render_connect<24>(ctx, n_srays, s);
+                else if (dep <= 32) launch_render_connect<32>(ctx, n_srays, s);
+                else if (dep <= 48) launch_render_connect<48>(ctx, n_srays, s);
+                else launch_render_connect<64>(ctx, n_srays, s);
+            }
+            const uint32_t nshade = n_ext + n_shp;
+            hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), 0, s, pl, sc, ra, pl.q_ext[cur], n_ext,
+                               pl.q_shpath[cur], n_shp, pl.q_ext[cur ^ 1], pl.q_shpath[cur ^ 1], ctx->d_counters);
+            PTMI_HIP(ctx, hipGetLastError());
+            PTMI_HIP(ctx, hipMemcpyAsync(hc, pl.qcnt, sizeof hc, hipMemcpyDeviceToHost, s));
+            PTMI_HIP(ctx, hipStreamSynchronize(s));
+            uint32_t n_free = (uint32_t)hc[Q_FREE];
+            uint32_t ne = (uint32_t)hc[Q_WORDS + Q_EXT];
+            n_shp = (uint32_t)hc[Q_WORDS + Q_SHADOW_PATHS];
+            n_srays = (uint32_t)hc[Q_SHADOW_RAYS];
+            // re-fill finished slots with fresh samples (appended to the next extend queue)
+            if (n_free && next_sample < ra.total) {
+                uint32_t ng = (uint32_t)std::min<uint64_t>(n_free, ra.total - next_sample);
+                hipLaunchKernelGGL(generate_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, pl, ra, (const uint32_t *)pl.q_free,
+                                   ng, next_sample, &pl.qcnt[Q_WORDS + Q_EXT], pl.q_ext[cur ^ 1]);
+                next_sample += ng;
+                ne += ng;
+            }
+            n_ext = ne;
+            cur ^= 1;
+        }
+        if (out_samples_host) {
+            PTMI_HIP(ctx, hipMemcpyAsync(out_samples_host, rs->d_out, ra.total * 12, hipMemcpyDeviceToHost, s));
+            PTMI_HIP(ctx, hipStreamSynchronize(s));
+        } else {
+            hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rs->d_out,
+                               (uint32_t)npix, chunk, d_accum, d_counts);
+            PTMI_HIP(ctx, hipGetLastError());
+        }
+    }
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_render_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t x0, int32_t y0,
+                               int32_t w, int32_t h, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
+                               uint32_t *counts, void *stream) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_render_dev: ctx is null");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_render_dev: no BVH");
+    if (!accum_rgb || !counts) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_dev: null buffer");
+    int rc = render_core(ctx, camera, params, x0, y0, w, h, spp_begin, spp_count, accum_rgb, counts, nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+    PTMI_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_render(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t x0, int32_t y0, int32_t w,
+                           int32_t h, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb, uint32_t *counts) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_render: ctx is null");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_render: no BVH");
+    if (!accum_rgb || !counts) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: null buffer");
+    RenderState *rs = ctx->render;
+    if (!rs || !rs->have_scene) return set_err(ctx, PTMI_ERR_NO_SCENE, "ptmi_render: no scene uploaded");
+    if (w <= 0 || h <= 0) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: empty rectangle");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)w * h;
+    if (rs->accum_pix < npix) {
+        if (rs->d_accum) (void)hipFree(rs->d_accum);
+        if (rs->d_counts) (void)hipFree(rs->d_counts);
+        rs->d_accum = nullptr; rs->d_counts = nullptr; rs->accum_pix = 0;
+        PTMI_HIP(ctx, hipMalloc((void **)&rs->d_accum, npix * 12));
+        PTMI_HIP(ctx, hipMalloc((void **)&rs->d_counts, npix * 4));
+        rs->accum_pix = npix;
+    }
+    hipStream_t s = ctx->stream;
+    PTMI_HIP(ctx, hipMemcpyAsync(rs->d_accum, accum_rgb, npix * 12, hipMemcpyHostToDevice, s));
+    PTMI_HIP(ctx, hipMemcpyAsync(rs->d_counts, counts, npix * 4, hipMemcpyHostToDevice, s));
+    int rc = render_core(ctx, camera, params, x0, y0, w, h, spp_begin, spp_count, rs->d_accum, rs->d_counts, nullptr, s);
+    if (rc) return rc;
+    PTMI_HIP(ctx, hipMemcpyAsync(accum_rgb, rs->d_accum, npix * 12, hipMemcpyDeviceToHost, s));
+    PTMI_HIP(ctx, hipMemcpyAsync(counts, rs->d_counts, npix * 4, hipMemcpyDeviceToHost, s));
+    PTMI_HIP(ctx, hipStreamSynchronize(s));
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_render_samples(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t x0, int32_t y0,
+                                   int32_t w, int32_t h, uint32_t spp_begin, uint32_t spp_count, float *out_rgb) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_render_samples: ctx is null");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_render_samples: no BVH");
+    if (!out_rgb) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_samples: null buffer");
+    if (w <= 0 || h <= 0) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_samples: empty rectangle");
+    if ((uint64_t)w * h * spp_count > (256ull << 20))
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_samples: more than 2^28 samples in one call");
+    return render_core(ctx, camera, params, x0, y0, w, h, spp_begin, spp_count, nullptr, nullptr, out_rgb, ctx->stream);
+}
+
+// vec3.go:95-106 + main.go:886-896
+extern "C" int ptmi_to_rgba(ptmi_ctx *ctx, const float *accum_rgb, const uint32_t *counts, int32_t width, int32_t height,
+                            uint8_t *rgba) {
+    if (!accum_rgb || !counts || !rgba || width <= 0 || height <= 0)
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_to_rgba: bad argument");
+    auto gomax = [](float a, float b) { return (a != a || b != b) ? NAN : (a > b ? a : b); };
+    auto gomin = [](float a, float b) { return (a != a || b != b) ? NAN : (a < b ? a : b); };
+    for (int Y = 0; Y < height; ++Y)
+        for (int X = 0; X < width; ++X) {
+            const size_t i = (size_t)Y * width + X;
+            const int ox = width - X;                           // main.go:896
+            if (ox < 0 || ox >= width || counts[i] == 0) continue;
+            const float n = (float)counts[i];
+            uint8_t *o = rgba + 4 * ((size_t)Y * width + ox);
+            for (int k = 0; k < 3; ++k) {
+                float c = accum_rgb[3 * i + k] / n;             // main.go:886-888
+                float v = gomax(0.0f, gomin(1.0f, std::sqrt(gomax(0.0f, c)))) * 255.0f;
+                o[k] = (v == v) ? (uint8_t)v : 0;
+            }
+            o[3] = 255;
+        }
+    return PTMI_OK;
+}

@@ -1,0 +1,269 @@
+// shade_device.hpp -- gfx950 device code for the integrator's shading math.
+//
+// Restates, in the reference's operand order and with FMA contraction off, the float32 helpers
+// TraceRay uses: vec3.go, utils.go:127-307, renderer.go:326-336, skybox.go, BlackHole.go.
+// Transcendentals (sin/cos/atan/atan2/acos/pow) come from the device math library, so images
+// match the CPU oracle to a tolerance, not bitwise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ptmi.h"
+#include "trav_device.hpp"
+
+namespace ptmi {
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 mk(const float *p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }       // vec3.go:22
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }       // vec3.go:32
+__device__ __forceinline__ V3 scale(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }        // vec3.go:42
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }    // vec3.go:52
+__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }                          // vec3.go:56
+__device__ __forceinline__ V3 normalize(V3 a) {                                                     // vec3.go:60
+    float len = length(a);
+    if (len == 0.0f) return mk(0, 0, 0);
+    return scale(a, 1.0f / len);
+}
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {                                                   // vec3.go:79
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 cmul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }      // vec3.go:108
+__device__ __forceinline__ V3 lerp(V3 a, V3 b, float t) { return add(a, scale(sub(b, a), t)); }     // vec3.go:134
+
+#define PT_PI32 ((float)3.14159265358979323846)
+
+// ---- counter-based RNG shared with the CPU oracle (replaces Go's global math/rand) ----
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+struct Rng { uint32_t key, ctr; };
+__device__ __forceinline__ Rng rng_init(uint32_t seed, uint32_t pixel, uint32_t sample) {
+    Rng r;
+    r.key = mix32(mix32(mix32(seed ^ 0xA511E9B3u) + pixel * 0x9E3779B9u) ^ (sample * 0x85EBCA6Bu + 0x27D4EB2Fu));
+    r.ctr = 0;
+    return r;
+}
+__device__ __forceinline__ uint32_t rng_u32(Rng &r) { return mix32(r.key + 0x9E3779B9u * (r.ctr++)); }
+__device__ __forceinline__ float rng_f32(Rng &r) { return (float)(rng_u32(r) >> 8) * (float)(1.0 / 16777216.0); }
+__device__ __forceinline__ uint32_t rng_intn(Rng &r, uint32_t n) {
+    return (uint32_t)(((unsigned long long)rng_u32(r) * (unsigned long long)n) >> 32);
+}
+
+// utils.go:127-151
+__device__ __forceinline__ V3 interpolate_normal(V3 p, V3 a, V3 b, V3 c, V3 nA, V3 nB, V3 nC) {
+    V3 v0 = sub(b, a), v1 = sub(c, a), v2 = sub(p, a);
+    float d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
+    float denom = d00 * d11 - d01 * d01;
+    float v = (d11 * d20 - d01 * d21) / denom;
+    float w = (d00 * d21 - d01 * d20) / denom;
+    float u = 1.0f - v - w;
+    nA = scale(nA, u); nB = scale(nB, v); nC = scale(nC, w);
+    nA = add(nA, nB); nA = add(nA, nC);
+    return nA;
+}
+// utils.go:217-229
+__device__ __forceinline__ V3 sample_triangle_point(Rng &r, V3 A, V3 B, V3 C) {
+    float u = rng_f32(r);
+    float v = rng_f32(r) * (1.0f - u);
+    float w = 1.0f - u - v;
+    A = scale(A, w); B = scale(B, v); C = scale(C, u);
+    A = add(A, B); A = add(A, C);
+    return A;
+}
+// utils.go:231-236
+__device__ __forceinline__ float triangle_area(V3 A, V3 B, V3 C) { return 0.5f * length(cross(sub(B, A), sub(C, A))); }
+
+// utils.go:242-253, tracer.go:625-634
+__device__ __forceinline__ void tangent_frame(V3 n, V3 &t1, V3 &t2) {
+    V3 up = fabsf(n.y) < (float)0.999 ? mk(0, 1, 0) : mk(1, 0, 0);
+    t1 = normalize(cross(n, up));
+    t2 = cross(n, t1);
+}
+// utils.go:255-270 / 273-290
+__device__ __forceinline__ V3 cosine_sample2(Rng &r, V3 n, V3 t1, V3 t2) {
+    float u1 = rng_f32(r), u2 = rng_f32(r);
+    float rr = sqrtf(u1);
+    float theta = (float)(2.0 * 3.14159265358979323846) * u2;
+    float x = rr * cosf(theta), y = rr * sinf(theta);
+    float z = sqrtf(gomaxf(0.0f, 1.0f - u1));
+    V3 d = scale(t1, x);
+    d = add(d, scale(t2, y));
+    d = add(d, scale(n, z));
+    return normalize(d);
+}
+// utils.go:292-294
+__device__ __forceinline__ V3 reflect_v(V3 V, V3 N) { return sub(V, scale(N, 2.0f * dot(V, N))); }
+// utils.go:296-307
+__device__ __forceinline__ V3 get_refracted_ray(V3 inDir, V3 inNormal, float n1, float n2, bool &tir) {
+    V3 A = normalize(inDir), N = normalize(inNormal);
+    float R = n1 / n2;
+    float c = -dot(A, N);
+    float D = 1.0f - R * R * (1.0f - c * c);
+    if (D < 0.0f) { tir = true; return reflect_v(inDir, inNormal); }
+    tir = false;
+    return normalize(add(scale(A, R), scale(N, c * R - sqrtf(D))));
+}
+// renderer.go:326-336
+__device__ __forceinline__ float mis_weight(float pdf1, float pdf2) {
+    if (pdf1 <= 0.0f) return 0.0f;
+    if (pdf2 <= 0.0f) return 1.0f;
+    float p1 = pdf1 * pdf1, p2 = pdf2 * pdf2;
+    return p1 / (p1 + p2);
+}
+// tracer.go:724-747
+__device__ __forceinline__ V3 sample_glossy(Rng &r, V3 reflDir, float roughness) {
+    V3 up = fabsf(reflDir.y) < (float)0.9 ? mk(0, 1, 0) : mk(1, 0, 0);
+    V3 t1 = normalize(cross(reflDir, up));
+    V3 t2 = normalize(cross(reflDir, t1));
+    float theta = rng_f32(r) * 2.0f * PT_PI32;
+    float alpha = roughness * roughness;
+    float u = rng_f32(r);
+    float phi = atanf(alpha * sqrtf(u) / sqrtf(1.0f - u));
+    float x = cosf(theta) * sinf(phi), y = sinf(theta) * sinf(phi), z = cosf(phi);
+    return normalize(add(add(scale(t1, x), scale(t2, y)), scale(reflDir, z)));
+}
+
+// skybox.go:23-25, 36-42, 70-107
+__device__ __forceinline__ V3 sky_sample(const PtSky &s, const uint16_t *img, V3 dir) {
+    if (s.kind == PTMI_SKY_SOLID) return mk(s.horizon);
+    if (s.kind == PTMI_SKY_GRADIENT) {
+        float angle = dot(dir, mk(0, 1, 0));
+        if (angle < 0.0f) return mk(s.ground);
+        return scale(add(scale(mk(s.horizon), 1.0f - angle), scale(mk(s.zenith), angle)), s.intensity);
+    }
+    if (s.kind == PTMI_SKY_IMAGE) {
+        V3 d = normalize(dir);
+        float phi = atan2f(d.z, d.x), theta = acosf(d.y);
+        float u = (phi + PT_PI32) / (2.0f * PT_PI32), v = theta / PT_PI32;
+        float fx = u * (float)(s.image_width - 1), fy = v * (float)(s.image_height - 1);
+        int x = (fx == fx) ? (int)fx : 0, y = (fy == fy) ? (int)fy : 0;
+        x = x < 0 ? 0 : (x > s.image_width - 1 ? s.image_width - 1 : x);
+        y = y < 0 ? 0 : (y > s.image_height - 1 ? s.image_height - 1 : y);
+        const uint16_t *p = img + 3 * ((size_t)y * s.image_width + x);
+        return scale(mk((float)p[0] / 65535.0f, (float)p[1] / 65535.0f, (float)p[2] / 65535.0f), s.intensity);
+    }
+    return mk(0, 0, 0);
+}
+
+// ---- BlackHole.go ------------------------------------------------------------------------------
+struct RayState { float px, py, pz, vx, vy, vz, pt, vt; };
+
+// BlackHole.go:24-69
+__device__ __forceinline__ RayState get_initial_state(V3 position, V3 direction, const PtBlackHole &bh) {
+    RayState z = {0, 0, 0, 0, 0, 0, 0, 0};
+    V3 rel = sub(position, mk(bh.position));
+    float r = length(rel);
+    if (r == 0.0f) return z;
+    float rs = bh.rs;
+    float p_dot_v = dot(rel, direction), v_dot_v = dot(direction, direction);
+    float A = rs / r - 1.0f;
+    float B = 2.0f * rs * p_dot_v / (r * r);
+    float C = v_dot_v + rs * p_dot_v * p_dot_v / (r * r * r);
+    float disc = B * B - 4.0f * A * C;
+    if (disc < 0.0f) return z;
+    RayState s;
+    s.vt = (-B + sqrtf(disc)) / (2.0f * A);
+    s.pt = 0.0f; s.px = rel.x; s.py = rel.y; s.pz = rel.z; s.vx = direction.x; s.vy = direction.y; s.vz = direction.z;
+    return s;
+}
+// BlackHole.go:74-110
+__device__ __forceinline__ void get_acceleration(const RayState &s, float rs, float &at, float &ax, float &ay, float &az) {
+    float px = s.px, py = s.py, pz = s.pz, vx = s.vx, vy = s.vy, vz = s.vz;
+    float r_sq = (px * px + py * py) + pz * pz;
+    if (r_sq <= rs * rs) { at = ax = ay = az = 0.0f; return; }
+    float r = sqrtf(r_sq);
+    float r_cubed = r_sq * r;
+    float inv_r_cubed = 1.0f / r_cubed;
+    float x_dot_v = (px * vx + py * vy) + pz * vz;
+    float x_dot_v_sq = x_dot_v * x_dot_v;
+    float rs_x_dot_v = rs * x_dot_v;
+    float two = 2.0f * x_dot_v * inv_r_cubed;
+    at = -2.0f * rs_x_dot_v * inv_r_cubed;
+    float factor = (1.0f - 3.0f * rs * x_dot_v_sq * inv_r_cubed) * inv_r_cubed;
+    float rs_inv_factor = -rs * factor;
+    ax = px * rs_inv_factor + rs * two * vx;
+    ay = py * rs_inv_factor + rs * two * vy;
+    az = pz * rs_inv_factor + rs * two * vz;
+}
+struct Rk4D { float at, ax, ay, az, vt, vx, vy, vz; };
+// BlackHole.go:118-127
+__device__ __forceinline__ RayState evaluate_rk4(const RayState &s, float dt, const Rk4D &k) {
+    RayState o;
+    o.pt = s.pt + k.vt * dt; o.px = s.px + k.vx * dt; o.py = s.py + k.vy * dt; o.pz = s.pz + k.vz * dt;
+    o.vt = s.vt + k.at * dt; o.vx = s.vx + k.ax * dt; o.vy = s.vy + k.ay * dt; o.vz = s.vz + k.az * dt;
+    return o;
+}
+// BlackHole.go:131-163
+__device__ __forceinline__ RayState rk4_step(const RayState &s, float h, float rs) {
+    Rk4D k1, k2, k3, k4;
+    get_acceleration(s, rs, k1.at, k1.ax, k1.ay, k1.az);
+    k1.vt = s.vt; k1.vx = s.vx; k1.vy = s.vy; k1.vz = s.vz;
+    RayState tmp = evaluate_rk4(s, h * 0.5f, k1);
+    get_acceleration(tmp, rs, k2.at, k2.ax, k2.ay, k2.az);
+    k2.vt = tmp.vt; k2.vx = tmp.vx; k2.vy = tmp.vy; k2.vz = tmp.vz;
+    tmp = evaluate_rk4(s, h * 0.5f, k2);
+    get_acceleration(tmp, rs, k3.at, k3.ax, k3.ay, k3.az);
+    k3.vt = tmp.vt; k3.vx = tmp.vx; k3.vy = tmp.vy; k3.vz = tmp.vz;
+    tmp = evaluate_rk4(s, h, k3);
+    get_acceleration(tmp, rs, k4.at, k4.ax, k4.ay, k4.az);
+    k4.vt = tmp.vt; k4.vx = tmp.vx; k4.vy = tmp.vy; k4.vz = tmp.vz;
+    float h6 = h / 6.0f;
+    RayState o;
+    o.pt = s.pt + h6 * (((k1.vt + 2.0f * k2.vt) + 2.0f * k3.vt) + k4.vt);
+    o.px = s.px + h6 * (((k1.vx + 2.0f * k2.vx) + 2.0f * k3.vx) + k4.vx);
+    o.py = s.py + h6 * (((k1.vy + 2.0f * k2.vy) + 2.0f * k3.vy) + k4.vy);
+    o.pz = s.pz + h6 * (((k1.vz + 2.0f * k2.vz) + 2.0f * k3.vz) + k4.vz);
+    o.vt = s.vt + h6 * (((k1.at + 2.0f * k2.at) + 2.0f * k3.at) + k4.at);
+    o.vx = s.vx + h6 * (((k1.ax + 2.0f * k2.ax) + 2.0f * k3.ax) + k4.ax);
+    o.vy = s.vy + h6 * (((k1.ay + 2.0f * k2.ay) + 2.0f * k3.ay) + k4.ay);
+    o.vz = s.vz + h6 * (((k1.az + 2.0f * k2.az) + 2.0f * k3.az) + k4.az);
+    return o;
+}
+
+// Gradient noise standing in for go-perlin's Noise2D(alpha=2, beta=2, n=4); same lattice hash as the oracle.
+__device__ __forceinline__ double grad2(int ix, int iy, double fx, double fy) {
+    uint32_t h = mix32((uint32_t)ix * 0x9E3779B9u ^ mix32((uint32_t)iy * 0x85EBCA6Bu + 0x165667B1u)) & 7u;
+    const double q = 0.70710678118654752;
+    double gx = h == 0 ? 1.0 : h == 1 ? -1.0 : h < 4 ? 0.0 : ((h & 1) ? -q : q);
+    double gy = h < 2 ? 0.0 : h == 2 ? 1.0 : h == 3 ? -1.0 : (h < 6 ? q : -q);
+    return gx * fx + gy * fy;
+}
+__device__ __forceinline__ double noise2(double x, double y) {
+    double flx = floor(x), fly = floor(y);
+    int ix = (int)flx, iy = (int)fly;
+    double fx = x - flx, fy = y - fly;
+    double sx = fx * fx * (3.0 - 2.0 * fx), sy = fy * fy * (3.0 - 2.0 * fy);
+    double a = grad2(ix, iy, fx, fy), b = grad2(ix + 1, iy, fx - 1.0, fy);
+    double c = grad2(ix, iy + 1, fx, fy - 1.0), d = grad2(ix + 1, iy + 1, fx - 1.0, fy - 1.0);
+    double u = a + sx * (b - a), v = c + sx * (d - c);
+    return u + sy * (v - u);
+}
+__device__ __forceinline__ double perlin_noise2d(double x, double y) {
+    double sc = 1.0, sum = 0.0;
+    for (int i = 0; i < 4; ++i) { sum += noise2(x, y) / sc; sc *= 2.0; x *= 2.0; y *= 2.0; }
+    return sum;
+}
+// BlackHole.go:174-242
+__device__ __forceinline__ V3 disk_color(const PtBlackHole &bh, V3 world) {
+    V3 rel = sub(world, mk(bh.position));
+    float radius = sqrtf(rel.x * rel.x + rel.z * rel.z);
+    float angle = atan2f(rel.z, rel.x);
+    float t = (radius - bh.disk_inner) / (bh.disk_outer - bh.disk_inner);
+    if (t < 0.0f) t = 0.0f;
+    if (t > 1.0f) t = 1.0f;
+    V3 hot = mk(1.0f, 1.0f, 0.85f), mid = mk(1.0f, 0.6f, 0.0f), cool = mk(0.8f, 0.1f, 0.0f);
+    V3 temp = t < 0.5f ? lerp(hot, mid, t * 2.0f) : lerp(mid, cool, (t - 0.5f) * 2.0f);
+    float intensity = 1.0f / (t * t + 0.1f);
+    temp = scale(temp, intensity);
+    float nx = (radius / bh.disk_outer) * 3.0f * 2.0f;
+    float ny = (angle / (float)(2.0 * 3.14159265358979323846)) * 3.0f;
+    float nv = (float)(perlin_noise2d((double)nx, (double)ny) + 1.0) / 2.0f;
+    nv = powf(nv, 5.0f);
+    return scale(temp, nv);
+}
+
+}  // namespace ptmi

@@ -1,0 +1,145 @@
+"""Host-side mirror of the reference's render seam (main.go:784-899, tile.go, renderer.go) over the C ABI.
+
+    r = Renderer(scene_data, device=0)                      # DecomposeObjects + BuildBVH + ConstructLinearBVH
+    fb = r.new_framebuffer(W, H)                            # the Pixel buffer: R,G,B sums + SampleCount
+    r.render_tile(fb, params, camera, (x0, y0, w, h), spp)  # one `calculate` worker's tile (main.go:832-899)
+    img = r.to_rgba(fb)                                     # Vec3.ToRGBA + the mirrored img.Set (main.go:886-896)
+
+The integrator runs entirely in libptmi.so (generate / extend / shade / connect / accumulate kernels).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import PtCamera, PtParams, check
+from .api import BuildBVH, ConstructLinearBVH, Context, LinearBVH, _ptr
+from .scenes import Camera, SceneData
+
+
+def make_params(width, height, bounces=2, scatter_rays=1, max_steps=1, ambient=0.0, step_size=1000.0, seed=1):
+    """main.go:441-452 (the committed literals are bounces=2, scatterRays=1, ambient=0, and for mesh scenes
+    maxSteps=1, stepSize=1000: main.go:34-38; the black-hole scene uses maxSteps=3000, stepSize=1)."""
+    return PtParams(int(width), int(height), int(bounces), int(scatter_rays), int(max_steps), float(ambient),
+                    float(step_size), int(seed) & 0xFFFFFFFF)
+
+
+def make_camera(cam: Camera) -> PtCamera:
+    c = PtCamera()
+    c.position[:] = cam.position
+    c.forward[:] = cam.forward
+    c.right[:] = cam.right
+    c.up[:] = cam.up
+    c.frustum_distance = cam.frustum
+    return c
+
+
+@dataclass
+class Framebuffer:
+    """The reference's [][]Pixel reduced to what AddSample keeps for output: sums and counts."""
+    accum: np.ndarray      # [H,W,3] f32  (Pixel.R,G,B)
+    counts: np.ndarray     # [H,W] u32    (Pixel.SampleCount)
+
+    @property
+    def mean(self):
+        return self.accum / np.maximum(self.counts, 1)[..., None].astype(np.float32)
+
+
+class Renderer:
+    def __init__(self, sc: SceneData, device=0, ctx: Context | None = None, threshold=4, depth=42):
+        self.sc = sc
+        self.ctx = ctx or Context(device)
+        self._lib = _lib.load()
+        # main.go:804: BuildBVH(vertices, tris, -1000, 1000, ..., 4, 42); :810 ConstructLinearBVH
+        self.box = BuildBVH(sc.verts, sc.tris, threshold=threshold, depth=depth)
+        self.bvh: LinearBVH = ConstructLinearBVH(self.box, ctx=self.ctx)
+        self.upload_scene(sc)
+
+    def upload_scene(self, sc: SceneData):
+        mats = np.ascontiguousarray(sc.materials, np.float32)
+        tm = np.ascontiguousarray(sc.tri_material, np.uint32)
+        nrm = np.ascontiguousarray(sc.normals, np.float32)
+        lights = np.ascontiguousarray(sc.lights, np.float32).reshape(-1, 12)
+        sky = np.ascontiguousarray(sc.sky, np.float32)
+        img = None if sc.sky_image is None else np.ascontiguousarray(sc.sky_image, np.uint16)
+        bh = None if sc.blackhole is None else np.ascontiguousarray(sc.blackhole, np.float32)
+        assert mats.shape[1] == 16 and nrm.shape[0] == 3 * tm.shape[0] == 3 * sc.tris.shape[0]
+        check(self._lib.ptmi_upload_scene(
+            self.ctx.handle, mats.ctypes.data_as(C.c_void_p), mats.shape[0], _ptr(tm, C.c_uint32), _ptr(nrm, C.c_float),
+            lights.ctypes.data_as(C.c_void_p) if lights.size else None, lights.shape[0],
+            sky.ctypes.data_as(C.c_void_p), _ptr(img, C.c_uint16) if img is not None else None,
+            bh.ctypes.data_as(C.c_void_p) if bh is not None else None), self.ctx.handle)
+
+    @staticmethod
+    def new_framebuffer(width, height) -> Framebuffer:
+        return Framebuffer(np.zeros((height, width, 3), np.float32), np.zeros((height, width), np.uint32))
+
+    def render_tile(self, fb: Framebuffer, params: PtParams, camera: Camera | PtCamera, rect=None, spp=32,
+                    spp_begin=0):
+        """One tile of the reference's schedule: every pixel of `rect` gets samples
+        [spp_begin, spp_begin+spp) (main.go:861-879), added to the framebuffer."""
+        cam = camera if isinstance(camera, PtCamera) else make_camera(camera)
+        x0, y0, w, h = rect or (0, 0, params.width, params.height)
+        acc = np.ascontiguousarray(fb.accum[y0:y0 + h, x0:x0 + w])
+        cnt = np.ascontiguousarray(fb.counts[y0:y0 + h, x0:x0 + w])
+        check(self._lib.ptmi_render(self.ctx.handle, C.byref(cam), C.byref(params), x0, y0, w, h, spp_begin, spp,
+                                    _ptr(acc, C.c_float), _ptr(cnt, C.c_uint32)), self.ctx.handle)
+        fb.accum[y0:y0 + h, x0:x0 + w] = acc
+        fb.counts[y0:y0 + h, x0:x0 + w] = cnt
+
+    def render(self, params: PtParams, camera, spp=32, splits=(4, 4)) -> Framebuffer:
+        """The reference's frame: splitsX x splitsY tiles (main.go:454-491), each rendered to spp samples."""
+        fb = self.new_framebuffer(params.width, params.height)
+        sx, sy = splits
+        tw, th = params.width // sx, params.height // sy
+        for i in range(sx * sy):
+            self.render_tile(fb, params, camera, ((i % sx) * tw, (i // sx) * th, tw, th), spp)
+        return fb
+
+    def render_device(self, accum, counts, params: PtParams, camera, rect=None, spp=32, spp_begin=0, stream=None):
+        """Device-resident accumulators (torch CUDA tensors: f32 [h,w,3], i32/u32 [h,w] of the rectangle)."""
+        cam = camera if isinstance(camera, PtCamera) else make_camera(camera)
+        x0, y0, w, h = rect or (0, 0, params.width, params.height)
+        s = C.c_void_p(stream) if stream else None
+        check(self._lib.ptmi_render_dev(self.ctx.handle, C.byref(cam), C.byref(params), x0, y0, w, h, spp_begin, spp,
+                                        accum.data_ptr(), counts.data_ptr(), s), self.ctx.handle)
+
+    def render_samples(self, params: PtParams, camera, rect=None, spp=1, spp_begin=0):
+        """Per-sample radiance [h,w,spp,3] (no accumulation) -- for fine-grained parity checks."""
+        cam = camera if isinstance(camera, PtCamera) else make_camera(camera)
+        x0, y0, w, h = rect or (0, 0, params.width, params.height)
+        out = np.zeros((h, w, spp, 3), np.float32)
+        check(self._lib.ptmi_render_samples(self.ctx.handle, C.byref(cam), C.byref(params), x0, y0, w, h, spp_begin,
+                                            spp, _ptr(out, C.c_float)), self.ctx.handle)
+        return out
+
+    def to_rgba(self, fb: Framebuffer) -> np.ndarray:
+        h, w = fb.counts.shape
+        rgba = np.zeros((h, w, 4), np.uint8)
+        rgba[..., 3] = 255
+        acc = np.ascontiguousarray(fb.accum, np.float32)
+        cnt = np.ascontiguousarray(fb.counts, np.uint32)
+        check(self._lib.ptmi_to_rgba(self.ctx.handle, _ptr(acc, C.c_float), _ptr(cnt, C.c_uint32), w, h,
+                                     _ptr(rgba, C.c_uint8)), self.ctx.handle)
+        return rgba
+
+
+def smoke_render(ctx: Context):
+    """Tiny render on the GPU checked against the CPU oracle (used by __graft_entry__.smoke)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import oracle_lib
+    from . import scenes
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    r = Renderer(sc, ctx=ctx)
+    p = make_params(48, 48, bounces=2, seed=5)
+    got = r.render_samples(p, sc.camera, spp=4)
+    osc = oracle_lib.OracleScene(sc)
+    want = osc.render_samples(sc.camera.as_array(), oracle_lib.OrcParams(48, 48, 2, 1, 1, 0.0, 1000.0, 5), spp_count=4)
+    err = np.abs(got - want) / (1.0 + np.abs(want))
+    assert np.isfinite(got).all() and float(err.max()) < 1e-3, f"render differs from the oracle: max rel err {err.max()}"
+    print(f"smoke render ok: 48x48x4 samples, max rel err vs oracle {err.max():.2e}")

@@ -360,16 +360,19 @@ class SceneData:
     materials: np.ndarray             # [nm,16] f32 rows, see MATERIAL_COLUMNS
     lights: np.ndarray                # [nl,12] f32 rows, see LIGHT_COLUMNS
     sky: np.ndarray                   # [16] f32, see SKY_COLUMNS
-    blackhole: np.ndarray | None = None   # [8] f32: pos xyz, Rs, has_disk, inner, outer, pad
+    blackhole: np.ndarray | None = None   # PtBlackHole: pos xyz, Rs, i32 has_disk, inner, outer, pad
+    sky_image: np.ndarray | None = None   # [h,w,3] u16 equirect image for sky kind 3
     camera: Camera | None = None
     names: list = field(default_factory=list)
 
 
-# material row: Kd rgb, Ks rgb, Ke rgb, Ni, Ns, flags, pad x4      (obj.go:63-79)
+# Rows are binary images of the C structs of include/ptmi.h (integer fields stored as their bits):
+# PtMaterial: Kd rgb, Ks rgb, Ke rgb, Ni, Ns, u32 flags, pad x4                      (obj.go:63-79)
 MATERIAL_COLUMNS = 16
-# light row: kind (0 sun, 1 point), color rgb, dir/pos xyz, intensity, pad x4  (lights.go:11-15,32-35)
+# PtLight: i32 kind (0 sun, 1 point), color rgb, dir/pos xyz, intensity, pad x4      (lights.go:11-15,32-35)
 LIGHT_COLUMNS = 12
-# sky: kind (0 none,1 solid,2 gradient), horizon rgb (or solid colour), zenith rgb, ground rgb, intensity
+# PtSky: i32 kind (0 none,1 solid,2 gradient,3 image), horizon rgb (or solid colour), zenith rgb, ground rgb,
+#        intensity, i32 image width, i32 image height, pad x3                        (skybox.go)
 SKY_COLUMNS = 16
 
 
@@ -380,13 +383,13 @@ def material(kd=(0.7, 0.7, 0.7), ks=(0, 0, 0), ke=(0, 0, 0), ni=1.0, ns=0.0, fla
     row[6:9] = ke
     row[9] = ni
     row[10] = ns
-    row[11] = np.float32(flags)
+    row[11:12].view(np.uint32)[0] = flags
     return row
 
 
 def sun(direction, intensity, color=(1, 1, 1)):
     row = np.zeros(LIGHT_COLUMNS, dtype=F32)
-    row[0] = 0
+    row[0:1].view(np.int32)[0] = 0
     row[1:4] = color
     row[4:7] = direction
     row[7] = intensity
@@ -395,7 +398,7 @@ def sun(direction, intensity, color=(1, 1, 1)):
 
 def point_light(position, intensity, color=(1, 1, 1)):
     row = np.zeros(LIGHT_COLUMNS, dtype=F32)
-    row[0] = 1
+    row[0:1].view(np.int32)[0] = 1
     row[1:4] = color
     row[4:7] = position
     row[7] = intensity
@@ -404,7 +407,7 @@ def point_light(position, intensity, color=(1, 1, 1)):
 
 def sky_gradient(horizon, zenith, ground, intensity):
     row = np.zeros(SKY_COLUMNS, dtype=F32)
-    row[0] = 2
+    row[0:1].view(np.int32)[0] = 2
     row[1:4] = horizon
     row[4:7] = zenith
     row[7:10] = ground
@@ -414,13 +417,24 @@ def sky_gradient(horizon, zenith, ground, intensity):
 
 def sky_solid(color):
     row = np.zeros(SKY_COLUMNS, dtype=F32)
-    row[0] = 1
+    row[0:1].view(np.int32)[0] = 1
     row[1:4] = color
     return row
 
 
 def sky_none():
     return np.zeros(SKY_COLUMNS, dtype=F32)
+
+
+def sky_image(img_u16, intensity):
+    """ImageSkybox (skybox.go:46-107): img_u16 [h,w,3] uint16 equirect image."""
+    row = np.zeros(SKY_COLUMNS, dtype=F32)
+    iv = row.view(np.int32)
+    iv[0] = 3
+    row[10] = intensity
+    iv[11] = img_u16.shape[1]
+    iv[12] = img_u16.shape[0]
+    return row
 
 
 def _sponza_sky():
@@ -478,8 +492,10 @@ def blackhole_scene(segments=256):
     missing nebula PNG."""
     v, f = annulus(300.0, 450.0, segments)
     nrm = np.tile(np.array([0, 1, 0], dtype=F32), (3 * f.shape[0], 1))
-    mats = np.stack([material(kd=(1, 1, 1), flags=MAT_ACCRETION)])
-    bh = np.array([0, 0, 0, 100.0, 1.0, 300.0, 450.0, 0.0], dtype=F32)
+    # Ks = 1: the reflective branch keeps the procedural diffuse colour (tracer.go:111, :207-222)
+    mats = np.stack([material(kd=(1, 1, 1), ks=(1, 1, 1), ns=1000.0, flags=MAT_ACCRETION)])
+    bh = np.array([0, 0, 0, 100.0, 0.0, 300.0, 450.0, 0.0], dtype=F32)
+    bh[4:5].view(np.int32)[0] = 1          # PtBlackHole.has_disk
     # SphericalAround(Vec3{}, 1500, theta=90deg, phi=83deg): camera.go:17-41 (argument names are swapped
     # there: radius, phi<-theta(90deg), theta<-phi(83deg))
     ph, th = 90.0 * 0.0174533, 83.0 * 0.0174533

@@ -148,3 +148,97 @@ def probe_aabb(minb, maxb, o, d, step):
     o = np.asarray(o, np.float32); d = np.asarray(d, np.float32)
     return np.float32(load().orc_probe_aabb(_p(minb, C.c_float), _p(maxb, C.c_float), _p(o, C.c_float),
                                             _p(d, C.c_float), np.float32(step)))
+
+
+# ----------------------------------------------------------------------------- integrator (orc_trace.c)
+class OrcParams(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("bounces", C.c_int), ("scatter_rays", C.c_int),
+                ("max_steps", C.c_int), ("ambient", C.c_float), ("step_size", C.c_float), ("seed", C.c_uint32)]
+
+
+def _load_trace():
+    lib = load()
+    if getattr(lib, "_trace_ready", False):
+        return lib
+    U16 = C.POINTER(C.c_uint16)
+    lib.orc_scene_create.restype = C.c_void_p
+    lib.orc_scene_create.argtypes = [C.c_void_p, _F, _U32, C.c_uint64, _F, _U32, _F, C.c_uint64, _F, C.c_uint64, _F,
+                                     U16, C.c_int, C.c_int, _F]
+    lib.orc_scene_free.restype = None
+    lib.orc_scene_free.argtypes = [C.c_void_p]
+    lib.orc_render.restype = None
+    lib.orc_render.argtypes = [C.c_void_p, _F, C.POINTER(OrcParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                               C.c_uint32, _F, _U32, _U64P, C.c_int]
+    lib.orc_render_samples.restype = None
+    lib.orc_render_samples.argtypes = [C.c_void_p, _F, C.POINTER(OrcParams), C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_uint32, C.c_uint32, _F, C.c_int]
+    lib.orc_to_rgba.restype = None
+    lib.orc_to_rgba.argtypes = [_F, _U32, C.c_int, C.c_int, _U8]
+    lib._trace_ready = True
+    return lib
+
+
+class OracleScene:
+    """Scene + BVH for the restated integrator (TraceRay & co)."""
+
+    def __init__(self, sc, bvh: OracleBVH | None = None):
+        self.lib = _load_trace()
+        self.sc = sc
+        self.bvh = bvh or OracleBVH(sc.verts, sc.tris)
+        self.verts = self.bvh.verts
+        self.tris = self.bvh.tris
+        self.normals = np.ascontiguousarray(sc.normals, np.float32)
+        self.tri_material = np.ascontiguousarray(sc.tri_material, np.uint32)
+        self.materials = np.ascontiguousarray(sc.materials, np.float32)
+        self.lights = np.ascontiguousarray(sc.lights, np.float32).reshape(-1, 12)
+        self.sky = np.ascontiguousarray(sc.sky, np.float32)
+        self.sky_img = None if getattr(sc, "sky_image", None) is None else np.ascontiguousarray(sc.sky_image, np.uint16)
+        self.bh = None if sc.blackhole is None else np.ascontiguousarray(sc.blackhole, np.float32)
+        img_p, iw, ih = None, 0, 0
+        if self.sky_img is not None:
+            img_p, ih, iw = _p(self.sky_img, C.c_uint16), self.sky_img.shape[0], self.sky_img.shape[1]
+        self.h = self.lib.orc_scene_create(self.bvh.h, _p(self.verts, C.c_float), _p(self.tris, C.c_uint32),
+                                           self.tris.shape[0], _p(self.normals, C.c_float),
+                                           _p(self.tri_material, C.c_uint32), _p(self.materials, C.c_float),
+                                           self.materials.shape[0],
+                                           _p(self.lights, C.c_float) if self.lights.size else None,
+                                           self.lights.shape[0], _p(self.sky, C.c_float), img_p, iw, ih,
+                                           _p(self.bh, C.c_float) if self.bh is not None else None)
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self.lib.orc_scene_free(h)
+
+    @staticmethod
+    def params(width, height, bounces=2, scatter_rays=1, max_steps=1, ambient=0.0, step_size=1000.0, seed=1):
+        return OrcParams(width, height, bounces, scatter_rays, max_steps, ambient, step_size, seed)
+
+    def render(self, cam, params, rect=None, spp_begin=0, spp_count=1, nthreads=8, accum=None, counts=None):
+        x0, y0, w, h = rect or (0, 0, params.width, params.height)
+        cam = np.ascontiguousarray(cam, np.float32)
+        accum = np.zeros((h, w, 3), np.float32) if accum is None else accum
+        counts = np.zeros((h, w), np.uint32) if counts is None else counts
+        cnt = np.zeros(4, np.uint64)
+        self.lib.orc_render(self.h, _p(cam, C.c_float), C.byref(params), x0, y0, w, h, spp_begin, spp_count,
+                            _p(accum, C.c_float), _p(counts, C.c_uint32), _p(cnt, C.c_uint64), nthreads)
+        return accum, counts, dict(closest=int(cnt[0]), any=int(cnt[1]), diffuse_events=int(cnt[2]),
+                                   samples=int(cnt[3]))
+
+    def render_samples(self, cam, params, rect=None, spp_begin=0, spp_count=1, nthreads=8):
+        x0, y0, w, h = rect or (0, 0, params.width, params.height)
+        cam = np.ascontiguousarray(cam, np.float32)
+        out = np.zeros((h, w, spp_count, 3), np.float32)
+        self.lib.orc_render_samples(self.h, _p(cam, C.c_float), C.byref(params), x0, y0, w, h, spp_begin, spp_count,
+                                    _p(out, C.c_float), nthreads)
+        return out
+
+
+def to_rgba(accum, counts):
+    lib = _load_trace()
+    h, w = counts.shape
+    rgba = np.zeros((h, w, 4), np.uint8)
+    rgba[..., 3] = 255
+    lib.orc_to_rgba(_p(np.ascontiguousarray(accum, np.float32), C.c_float),
+                    _p(np.ascontiguousarray(counts, np.uint32), C.c_uint32), w, h, _p(rgba, C.c_uint8))
+    return rgba
