@@ -63,8 +63,11 @@ class Box:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            _lib.load().ptmi_host_bvh_free(h)
+        try:
+            if h:
+                _lib.load().ptmi_host_bvh_free(h)
+        except Exception:       # interpreter shutdown: module globals may already be gone
+            pass
 
     def GetStats(self) -> PtBvhStats:
         """bvh.go:117-146 (called as GetStats(1) at main.go:809)."""
@@ -116,7 +119,10 @@ class Context:
             _lib.load().ptmi_destroy(c)
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
 
     @property
     def handle(self):
