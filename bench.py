@@ -116,8 +116,65 @@ def cpu_baseline(wl, args):
             "gpu_mismatches_on_sample": mism}
 
 
+def render_leg(args, rank, world, dist, dev, torch):
+    """Secondary figure (not `value`): samples/s of the full wavefront integrator on BASELINE.json configs[2]
+    (C3: glass + emissive + gradient sky, 1920x1080, 256 spp, bounces 2).  With N > 1 the frame is sharded by
+    64x64 tiles over the ranks and reduced onto rank 0 with RCCL (strong scaling)."""
+    from pathtrace_amd import scenes, sharded
+    from pathtrace_amd.render import Renderer, make_params
+    sc = scenes.bunny_scene(blob_level=6, glass=True, emissive=True)
+    r = Renderer(sc, device=dev.index)
+    W, H, spp = args.render_width, args.render_height, args.render_spp
+    p = make_params(W, H, bounces=2, scatter_rays=1, max_steps=1, step_size=1000.0, seed=1)
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    rr = sharded.make_device_render_rect(r, p, sc.camera, stream)
+    # tiles of one rank are merged into row strips of full-width rows where possible: use row-interleaved strips
+    def run(spp_):
+        acc.zero_(); cnt.zero_()
+        rects = sharded.my_tiles(W, H, world, rank, tile=64) if world > 1 else [(0, 0, W, H)]
+        for rect in sharded.merge_rects(rects):
+            rr(acc, cnt, rect, 0, spp_)
+        if dist is not None:
+            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(cnt, dst=0, op=dist.ReduceOp.SUM)
+    run(1)                                   # warm-up: pool allocation, RCCL channel set-up
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    r.bvh.reset_counters()
+    t0 = time.perf_counter()
+    run(spp)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    c = r.bvh.counters()
+    q = torch.tensor([dt, float(c.closest_queries), float(c.any_queries), float(c.diffuse_events)], dtype=torch.float64,
+                     device=dev)
+    if dist is not None:
+        mx = q.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(q, op=dist.ReduceOp.SUM)
+        q[0] = mx[0]
+    q = q.cpu().tolist()
+    complete = bool((cnt == spp).all().item()) if rank == 0 else True
+    return {"metric": "samples/s, full multi-bounce integrator", "value": round(W * H * spp / q[0] / 1e6, 2),
+            "unit": "Msamples/s", "seconds": round(q[0], 4),
+            "config": {"workload": "C3: blob + glass spheres + emissive quad + mirror sphere, gradient sky + sun "
+                                   "(BASELINE.json configs[2])", "width": W, "height": H, "spp": spp, "bounces": 2,
+                       "triangles": int(sc.tris.shape[0]),
+                       "sharding": "single GPU" if world == 1 else f"64x64 tiles round-robin over {world} ranks + RCCL reduce"},
+            "closest_hit_Mqueries_per_s": round(q[1] / q[0] / 1e6, 1), "any_hit_Mqueries_per_s": round(q[2] / q[0] / 1e6, 1),
+            "diffuse_events_M_per_s": round(q[3] / q[0] / 1e6, 1), "frame_complete": complete}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--no-render", action="store_true", help="skip the secondary samples/s figure")
+    ap.add_argument("--render-width", type=int, default=1920)
+    ap.add_argument("--render-height", type=int, default=1080)
+    ap.add_argument("--render-spp", type=int, default=256)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -185,6 +242,10 @@ def main():
     else:
         total_rays = float(n)
 
+    render = None
+    if not args.no_render:
+        render = render_leg(args, rank, world, dist, dev, torch)
+
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -218,6 +279,8 @@ def main():
                          "inner_visits_per_ray": round(c.inner_visits / n, 3),
                          "tri_tests_per_ray": round(c.tri_tests / n, 3)},
         }
+        if render is not None:
+            out["render"] = render
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args)
         print(json.dumps(out), flush=True)
