@@ -278,6 +278,7 @@ BvhStats linear_bvh_stats(const LinearBVH &bvh) {
 int pack_bvh(const LinearBVH &bvh, const float *verts, const uint32_t *tri_idx, PackedBVH &out, const char **msg) {
     const size_t nn = bvh.nodes.size();
     out.nodes.clear(); out.tris.clear();
+    out.bounds_finite = true;
     // triangle records in leaf order
     out.tris.resize(bvh.tri_ids.size());
     for (size_t i = 0; i < nn; ++i) {
@@ -312,6 +313,9 @@ int pack_bvh(const LinearBVH &bvh, const float *verts, const uint32_t *tri_idx, 
             p.c0min[x] = c0.minb[x]; p.c0max[x] = c0.maxb[x];
             p.c1min[x] = c1.minb[x]; p.c1max[x] = c1.maxb[x];
         }
+        for (int x = 0; x < 3; ++x)
+            if (!std::isfinite(p.c0min[x]) || !std::isfinite(p.c0max[x]) || !std::isfinite(p.c1min[x]) || !std::isfinite(p.c1max[x]))
+                out.bounds_finite = false;
         p.ref0 = ref_of(i + 1); p.ref1 = ref_of(n.second_child);
         p.pad0 = p.pad1 = 0;
     }

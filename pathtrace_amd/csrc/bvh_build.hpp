@@ -56,6 +56,7 @@ struct PackedBVH {
     std::vector<PackedTri> tris;
     uint32_t root_ref = REF_EMPTY_LEAF;
     int max_depth = 0;              // levels, root = 1
+    bool bounds_finite = true;      // no NaN / Inf in any child box
 };
 
 // Returns 0 or a negative error; msg set on error.

@@ -4,7 +4,9 @@
 // and `connect` (any hit, replaces QuickCheckIntersection, linear_bvh.go:202) over caller-provided
 // ray arrays.  One ray per lane, one wave per workgroup (a finished wave frees its slot without
 // waiting for neighbours), traversal stack in LDS.
+#include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 #include "ptmi_ctx.hpp"
@@ -71,6 +73,88 @@ __global__ __launch_bounds__(WAVE) void extend_kernel(DevBVH bvh, const float *_
     flush_counters<COUNT>(cnt, counters, CNT_CLOSEST, live ? 1u : 0u);
 }
 
+// Variant 1: same launch shape, while-while loop with the NaN-free slab fast path.
+template <int STACK, bool COUNT>
+__global__ __launch_bounds__(WAVE) void extend_ww_kernel(DevBVH bvh, const float *__restrict__ o,
+                                                         const float *__restrict__ d, const float *__restrict__ tmax,
+                                                         uint64_t n, int32_t *__restrict__ prim, float *__restrict__ t,
+                                                         unsigned long long *counters) {
+    __shared__ uint32_t smem[STACK * WAVE];
+    const uint64_t r = (uint64_t)blockIdx.x * WAVE + threadIdx.x;
+    TravCounters cnt;
+    const bool live = r < n;
+    if (live) {
+        const float ox = o[3 * r], oy = o[3 * r + 1], oz = o[3 * r + 2];
+        const float dx = d[3 * r], dy = d[3 * r + 1], dz = d[3 * r + 2];
+        int p; float tt;
+        closest_hit_ww<WAVE, COUNT>(bvh, smem + threadIdx.x, ox, oy, oz, dx, dy, dz, tmax[r], p, tt, cnt);
+        prim[r] = p; t[r] = tt;
+    }
+    flush_counters<COUNT>(cnt, counters, CNT_CLOSEST, live ? 1u : 0u);
+}
+
+// Variant 2: persistent waves that re-fill finished lanes with fresh rays (one atomic per refill), so a
+// wave's lanes stay busy although ray lengths vary.  Every wave leaves the loop once the ray counter has
+// passed n and its own lanes have drained.
+template <int STACK, bool COUNT>
+__global__ __launch_bounds__(WAVE) void extend_persistent_kernel(DevBVH bvh, const float *__restrict__ o,
+                                                                 const float *__restrict__ d,
+                                                                 const float *__restrict__ tmax, uint64_t n,
+                                                                 int32_t *__restrict__ prim, float *__restrict__ t,
+                                                                 unsigned long long *counters,
+                                                                 unsigned long long *next_ray, int REFILL_BELOW) {
+    __shared__ uint32_t smem[STACK * WAVE];
+    uint32_t *stack_base = smem + threadIdx.x;
+    const int lane = threadIdx.x;
+    TravCounters cnt;
+    RayTrav r;
+    r.cur = D_REF_DONE; r.exact = false; r.sp = 0; r.best = -1; r.best_t = 0.0f;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+    uint64_t my_ray = 0;
+    bool has_ray = false, exhausted = false;
+    uint32_t nrays = 0;
+    for (;;) {
+        // ---- refill idle lanes ----
+        if (!exhausted) {
+            const unsigned long long idle = __ballot(!has_ray);
+            const uint32_t nidle = (uint32_t)__popcll(idle);
+            if (nidle) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(next_ray, (unsigned long long)nidle);
+                base = __shfl((long long)base, 0);
+                if (base + nidle >= n) exhausted = true;
+                if (!has_ray) {
+                    const uint64_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                    if (idx < n) {
+                        my_ray = idx; has_ray = true; ++nrays;
+                        trav_init(r, bvh, o[3 * idx], o[3 * idx + 1], o[3 * idx + 2], d[3 * idx], d[3 * idx + 1],
+                                  d[3 * idx + 2], tmax[idx]);
+                    }
+                }
+            }
+        }
+        if (!__any(has_ray)) break;
+        // ---- traverse until too few lanes are left (then refill) ----
+        for (;;) {
+            const bool exact = __any(has_ray && r.exact);
+            if (exact) {
+                while (has_ray && !(r.cur & D_REF_LEAF_BIT)) inner_step<WAVE, COUNT, true>(bvh, stack_base, r, cnt);
+            } else {
+                while (has_ray && !(r.cur & D_REF_LEAF_BIT)) inner_step<WAVE, COUNT, false>(bvh, stack_base, r, cnt);
+            }
+            if (has_ray && r.cur != D_REF_DONE) leaf_step<WAVE, COUNT>(bvh, stack_base, r, cnt);
+            if (has_ray && r.cur == D_REF_DONE) {
+                prim[my_ray] = r.best;
+                t[my_ray] = r.best >= 0 ? r.best_t : 0.0f;
+                has_ray = false;
+            }
+            const uint32_t nactive = (uint32_t)__popcll(__ballot(has_ray));
+            if (nactive == 0 || (!exhausted && nactive < (uint32_t)REFILL_BELOW)) break;
+        }
+    }
+    flush_counters<COUNT>(cnt, counters, CNT_CLOSEST, nrays);
+}
+
 template <int STACK, bool COUNT>
 __global__ __launch_bounds__(WAVE) void connect_kernel(DevBVH bvh, const float *__restrict__ o,
                                                        const float *__restrict__ d, const float *__restrict__ tmax,
@@ -92,6 +176,27 @@ template <int STACK>
 static void launch_extend(ptmi_ctx *ctx, const float *o, const float *d, const float *tmax, uint64_t n, int32_t *prim,
                           float *t, hipStream_t s) {
     dim3 grid((unsigned)((n + WAVE - 1) / WAVE)), block(WAVE);
+    if (ctx->extend_variant == 2) {
+        unsigned long long *next_ray = ctx->d_counters + CNT_NEXT_RAY;
+        (void)hipMemsetAsync(next_ray, 0, sizeof(unsigned long long), s);
+        dim3 pgrid((unsigned)std::min<uint64_t>(grid.x, (uint64_t)ctx->num_cus * ctx->persist_waves_per_cu));
+        if (ctx->counting)
+            hipLaunchKernelGGL((extend_persistent_kernel<STACK, true>), pgrid, block, 0, s, ctx->dev_bvh(), o, d,
+                               tmax, n, prim, t, ctx->d_counters, next_ray, ctx->persist_refill_below);
+        else
+            hipLaunchKernelGGL((extend_persistent_kernel<STACK, false>), pgrid, block, 0, s, ctx->dev_bvh(), o, d,
+                               tmax, n, prim, t, ctx->d_counters, next_ray, ctx->persist_refill_below);
+        return;
+    }
+    if (ctx->extend_variant == 1) {
+        if (ctx->counting)
+            hipLaunchKernelGGL((extend_ww_kernel<STACK, true>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t,
+                               ctx->d_counters);
+        else
+            hipLaunchKernelGGL((extend_ww_kernel<STACK, false>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t,
+                               ctx->d_counters);
+        return;
+    }
     if (ctx->counting)
         hipLaunchKernelGGL((extend_kernel<STACK, true>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t,
                            ctx->d_counters);
@@ -129,6 +234,14 @@ extern "C" int ptmi_create(int device, ptmi_ctx **out) {
     ptmi_ctx *ctx = new (std::nothrow) ptmi_ctx();
     if (!ctx) return set_err(nullptr, PTMI_ERR_OOM, "ptmi_create: out of host memory");
     ctx->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->num_cus = prop.multiProcessorCount;
+        if (const char *v = getenv("PTMI_EXTEND_VARIANT")) ctx->extend_variant = atoi(v);
+        if (const char *v = getenv("PTMI_REFILL_BELOW")) ctx->persist_refill_below = std::max(1, std::min(64, atoi(v)));
+        if (const char *v = getenv("PTMI_PERSIST_WAVES_PER_CU")) ctx->persist_waves_per_cu = std::max(1, atoi(v));
+    }
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
         (e = hipMalloc((void **)&ctx->d_counters, CNT_WORDS * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(ctx->d_counters, 0, CNT_WORDS * sizeof(unsigned long long))) != hipSuccess) {
@@ -176,6 +289,7 @@ static int upload_packed(ptmi_ctx *ctx, const float *verts, uint64_t nverts, con
     if (nb) PTMI_HIP(ctx, hipMemcpy(ctx->d_nodes, packed.nodes.data(), nb, hipMemcpyHostToDevice));
     if (tb) PTMI_HIP(ctx, hipMemcpy(ctx->d_tris, packed.tris.data(), tb, hipMemcpyHostToDevice));
     ctx->root_ref = packed.root_ref;
+    ctx->bounds_finite = packed.bounds_finite ? 1u : 0u;
     ctx->max_depth = packed.max_depth;
     ctx->packed_inner = packed.nodes.size();
     ctx->packed_tris = packed.tris.size();

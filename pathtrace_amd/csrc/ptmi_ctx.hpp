@@ -12,6 +12,7 @@
 // indices into the device counter block (unsigned long long each)
 enum {
     CNT_CLOSEST = 0, CNT_ANY = 1, CNT_INNER = 2, CNT_TRI = 3, CNT_LEAF = 4, CNT_DIFFUSE = 5, CNT_SAMPLES = 6,
+    CNT_NEXT_RAY = 7,      // ray cursor of the persistent extend kernel (reset before each launch)
     CNT_WORDS = 8
 };
 
@@ -29,6 +30,7 @@ struct ptmi_ctx {
     float4 *d_nodes = nullptr;
     float4 *d_tris = nullptr;
     uint32_t root_ref = ptmi::D_REF_EMPTY_LEAF;
+    uint32_t bounds_finite = 0;
     std::vector<float> verts;          // kept for the scene upload (emissive sampling, normals)
     std::vector<uint32_t> tri_idx;
 
@@ -40,11 +42,17 @@ struct ptmi_ctx {
     // scene + wavefront integrator state (ptmi_render.hip)
     struct RenderState *render = nullptr;
 
+    // extend kernel selection (0 = if-if one-shot, 1 = while-while + fast slab, 2 = persistent with ray refill)
+    int extend_variant = 0;
+    int persist_waves_per_cu = 16;
+    int persist_refill_below = 40;      // refill a wave's idle lanes once fewer than this many are active
+    int num_cus = 256;
+
     // work counters
     bool counting = false;
     unsigned long long *d_counters = nullptr;
 
-    ptmi::DevBVH dev_bvh() const { return ptmi::DevBVH{d_nodes, d_tris, root_ref}; }
+    ptmi::DevBVH dev_bvh() const { return ptmi::DevBVH{d_nodes, d_tris, root_ref, bounds_finite}; }
 };
 
 namespace ptmi {

@@ -19,6 +19,7 @@ struct DevBVH {
     const float4 *nodes;   // 4 x float4 per packed inner node
     const float4 *tris;    // 3 x float4 per packed triangle
     uint32_t root_ref;
+    uint32_t bounds_finite;   // every child box of every packed node is finite (enables slab_fast)
 };
 
 // Go builtin max/min (NaN if either operand is NaN).  The sign of a zero result is not
@@ -158,6 +159,116 @@ __device__ __forceinline__ void closest_hit(const DevBVH &bvh, uint32_t *stack_b
     }
     prim_out = best;
     t_out = best >= 0 ? best_t : 0.0f;
+}
+
+// ---- step-wise form of the same walk (used by the persistent / refilling kernels) -------------------
+//
+// slab_fast: linear_bvh.go:23-70 for rays whose slab products cannot be NaN.  A product (bound - o) * inv
+// is NaN only for 0*inf, inf*0 or NaN inputs; with finite bounds (checked at upload), finite origin, finite
+// step and finite 1/d every product is finite or +-inf, and on non-NaN values Go's min/max and the
+// `if t1 > t2 swap` reduce to plain min/max (the sign of a zero distance is never observable).  Rays that
+// do not qualify (a zero / denormal direction component, non-finite input) take the exact `slab`.
+__device__ __forceinline__ float slab_fast(float minx, float miny, float minz, float maxx, float maxy, float maxz,
+                                           float ox, float oy, float oz, float ix, float iy, float iz, float step) {
+    float t1 = (minx - ox) * ix, t2 = (maxx - ox) * ix;
+    float lo = fminf(t1, t2), hi = fmaxf(t1, t2);
+    t1 = (miny - oy) * iy; t2 = (maxy - oy) * iy;
+    lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2));
+    t1 = (minz - oz) * iz; t2 = (maxz - oz) * iz;
+    lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2));
+    const bool miss = lo > fminf(hi, step) || hi < 0.0f;
+    return miss ? PT_INF : fmaxf(0.0f, lo);
+}
+
+constexpr uint32_t D_REF_DONE = 0xFFFFFFFEu;     // traversal finished (has the leaf bit, never a real leaf)
+
+struct RayTrav {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;
+    float best_t;
+    int best;
+    uint32_t cur;
+    int sp;
+    bool exact;          // needs the NaN-exact slab
+};
+
+__device__ __forceinline__ bool finitef(float x) { return fabsf(x) <= PT_INF; }   // false for NaN and +-Inf
+
+__device__ __forceinline__ void trav_init(RayTrav &r, const DevBVH &bvh, float ox, float oy, float oz, float dx, float dy,
+                                          float dz, float step) {
+    r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
+    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;        // Inverse() (vec3.go:118-124)
+    r.best_t = step; r.best = -1; r.cur = bvh.root_ref; r.sp = 0;
+    r.exact = !(finitef(r.ix) && finitef(r.iy) && finitef(r.iz) && finitef(ox) && finitef(oy) && finitef(oz) &&
+                finitef(step)) || !bvh.bounds_finite;
+}
+
+// one inner node of CheckIntersection (linear_bvh.go:138-162); r.cur must be an inner reference
+template <int BLOCK, bool COUNT, bool EXACT>
+__device__ __forceinline__ void inner_step(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
+    if (COUNT) cnt.inner++;
+    const float4 *p = bvh.nodes + (size_t)r.cur * 4;
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    float d1, d2;
+    if (EXACT) {
+        d1 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.best_t);
+        d2 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.best_t);
+    } else {
+        d1 = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.best_t);
+        d2 = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.best_t);
+    }
+    uint32_t i = __float_as_uint(q3.x), j = __float_as_uint(q3.y);
+    if (d1 > d2) { uint32_t ti = i; i = j; j = ti; float td = d1; d1 = d2; d2 = td; }   // :148-151
+    if (d1 == PT_INF) {                                                                  // :152-154
+        if (r.sp == 0) { r.cur = D_REF_DONE; return; }
+        --r.sp; r.cur = stack_base[r.sp * BLOCK];
+        return;
+    }
+    if (d2 < r.best_t) { stack_base[r.sp * BLOCK] = j; ++r.sp; }                         // :156-159
+    r.cur = i;                                                                           // :160
+}
+
+// one leaf of CheckIntersection (linear_bvh.go:129-137), then pop; r.cur must be a leaf reference (not DONE)
+template <int BLOCK, bool COUNT>
+__device__ __forceinline__ void leaf_step(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
+    if (COUNT) cnt.leaf++;
+    if (r.cur != D_REF_EMPTY_LEAF) {
+        const float4 *p = bvh.tris + (size_t)(r.cur & 0x7FFFFFFFu) * 3;
+        for (;;) {
+            const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+            if (COUNT) cnt.tri++;
+            float t;
+            bool hit = segment_triangle(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.best_t, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y,
+                                        r1.z, r1.w, r2.x, t);
+            if (hit && t < r.best_t && t > 0.0f) { r.best_t = t; r.best = (int)__float_as_uint(r2.y); }   // :133-136
+            if (__float_as_uint(r2.z) == 0u) break;
+            p += 3;
+        }
+    }
+    if (r.sp == 0) { r.cur = D_REF_DONE; return; }
+    --r.sp; r.cur = stack_base[r.sp * BLOCK];
+}
+
+// CheckIntersection, while-while form over the steps above; the wave takes the exact slab only when one
+// of its rays needs it.
+template <int BLOCK, bool COUNT>
+__device__ __forceinline__ void closest_hit_ww(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
+                                               float dx, float dy, float dz, float step, int &prim_out, float &t_out,
+                                               TravCounters &cnt) {
+    RayTrav r;
+    trav_init(r, bvh, ox, oy, oz, dx, dy, dz, step);
+    if (__any(r.exact)) {
+        while (r.cur != D_REF_DONE) {
+            while (!(r.cur & D_REF_LEAF_BIT)) inner_step<BLOCK, COUNT, true>(bvh, stack_base, r, cnt);
+            if (r.cur != D_REF_DONE) leaf_step<BLOCK, COUNT>(bvh, stack_base, r, cnt);
+        }
+    } else {
+        while (r.cur != D_REF_DONE) {
+            while (!(r.cur & D_REF_LEAF_BIT)) inner_step<BLOCK, COUNT, false>(bvh, stack_base, r, cnt);
+            if (r.cur != D_REF_DONE) leaf_step<BLOCK, COUNT>(bvh, stack_base, r, cnt);
+        }
+    }
+    prim_out = r.best;
+    t_out = r.best >= 0 ? r.best_t : 0.0f;
 }
 
 // QuickCheckIntersection (linear_bvh.go:202-250)
