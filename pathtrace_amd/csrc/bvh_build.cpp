@@ -280,7 +280,10 @@ int pack_bvh(const LinearBVH &bvh, const float *verts, const uint32_t *tri_idx, 
     out.nodes.clear(); out.tris.clear();
     out.bounds_finite = true;
     // triangle records in leaf order
-    out.tris.resize(bvh.tri_ids.size());
+    // + one degenerate record (all zero: det = 0 or NaN, never a hit in either triangle test) that empty
+    // leaves reference, so the kernels need no empty-leaf case
+    out.tris.assign(bvh.tri_ids.size() + 1, PackedTri{});
+    out.dummy_tri = (uint32_t)bvh.tri_ids.size();
     for (size_t i = 0; i < nn; ++i) {
         const LinNode &n = bvh.nodes[i];
         if (!n.is_leaf) continue;
@@ -289,18 +292,21 @@ int pack_bvh(const LinearBVH &bvh, const float *verts, const uint32_t *tri_idx, 
             PackedTri &t = out.tris[n.tri_offset + k];
             const float *a = verts + 3ull * tri_idx[3ull * id], *b = verts + 3ull * tri_idx[3ull * id + 1],
                         *c = verts + 3ull * tri_idx[3ull * id + 2];
-            for (int x = 0; x < 3; ++x) { t.A[x] = a[x]; t.B[x] = b[x]; t.C[x] = c[x]; }
+            t.BCx[0] = b[0]; t.BCx[1] = c[0]; t.BCy[0] = b[1]; t.BCy[1] = c[1]; t.BCz[0] = b[2]; t.BCz[1] = c[2];
+            t.Axy[0] = a[0]; t.Axy[1] = a[1]; t.Az = a[2];
             t.prim = id; t.nleft = n.tri_count - 1 - k; t.pad = 0;
         }
     }
     // inner nodes numbered in pre-order
+    // inner nodes numbered in pre-order (a first child sits right after its parent, half the time in the
+    // same 128-byte line)
     std::vector<uint32_t> inner_index(nn, 0);
     uint32_t ninner = 0;
     for (size_t i = 0; i < nn; ++i) if (!bvh.nodes[i].is_leaf) inner_index[i] = ninner++;
     auto ref_of = [&](size_t i) -> uint32_t {
         const LinNode &n = bvh.nodes[i];
         if (!n.is_leaf) return inner_index[i];
-        if (n.tri_count == 0) return REF_EMPTY_LEAF;
+        if (n.tri_count == 0) return REF_LEAF_BIT | out.dummy_tri;
         return REF_LEAF_BIT | n.tri_offset;
     };
     out.nodes.resize(ninner);
@@ -309,13 +315,13 @@ int pack_bvh(const LinearBVH &bvh, const float *verts, const uint32_t *tri_idx, 
         if (n.is_leaf) continue;
         PackedNode &p = out.nodes[inner_index[i]];
         const LinNode &c0 = bvh.nodes[i + 1], &c1 = bvh.nodes[n.second_child];
+        float *axis[3] = {p.x, p.y, p.z};
         for (int x = 0; x < 3; ++x) {
-            p.c0min[x] = c0.minb[x]; p.c0max[x] = c0.maxb[x];
-            p.c1min[x] = c1.minb[x]; p.c1max[x] = c1.maxb[x];
+            axis[x][0] = c0.minb[x]; axis[x][1] = c0.maxb[x];
+            axis[x][2] = c1.minb[x]; axis[x][3] = c1.maxb[x];
+            for (int k = 0; k < 4; ++k)
+                if (!std::isfinite(axis[x][k])) out.bounds_finite = false;
         }
-        for (int x = 0; x < 3; ++x)
-            if (!std::isfinite(p.c0min[x]) || !std::isfinite(p.c0max[x]) || !std::isfinite(p.c1min[x]) || !std::isfinite(p.c1max[x]))
-                out.bounds_finite = false;
         p.ref0 = ref_of(i + 1); p.ref1 = ref_of(n.second_child);
         p.pad0 = p.pad1 = 0;
     }

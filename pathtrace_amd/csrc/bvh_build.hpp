@@ -26,13 +26,15 @@ struct BvhStats {   // bvh.go:109-146
     int64_t max_depth = 0, max_tris = 0, min_tris = 0, total_leafs = 0, total_nodes = 0, total_triangles = 0;
 };
 
-// 64-byte packed inner node: both children's boxes + child references.
-//   ref: bit 31 set  -> leaf; low 31 bits = offset of its first triangle record
-//        0xFFFFFFFF  -> empty leaf (no triangle records)
+// 64-byte packed inner node: both children's boxes + child references, one axis per 16-byte
+// quarter (min,max of child 0, min,max of child 1).
+//   ref: bit 31 set  -> leaf; low 31 bits = offset of its first triangle record (an empty
+//                       leaf points at the shared degenerate record PackedBVH::dummy_tri)
 //        bit 31 clear -> index of a packed inner node
 struct alignas(64) PackedNode {
-    float c0min[3], c0max[3];
-    float c1min[3], c1max[3];
+    float x[4];        // c0min.x c0max.x c1min.x c1max.x
+    float y[4];
+    float z[4];
     uint32_t ref0, ref1;
     uint32_t pad0, pad1;
 };
@@ -40,8 +42,11 @@ static_assert(sizeof(PackedNode) == 64, "packed node must be one 64-byte fetch")
 
 // 48-byte triangle record, stored in leaf (DFS) order.  A,B,C verbatim (edges are NOT
 // precomputed so that edge1 = B - A is evaluated exactly as utils.go:70-71 does).
+// Layout pairs B with C per axis: (B.x,C.x) - (A.x,A.x) = (edge1.x, edge2.x) is one packed subtract.
 struct alignas(16) PackedTri {
-    float A[3], B[3], C[3];
+    float BCx[2], BCy[2];          // B.x C.x B.y C.y
+    float BCz[2], Axy[2];          // B.z C.z A.x A.y
+    float Az;
     uint32_t prim;      // tri.Index/3
     uint32_t nleft;     // triangles that follow this one in the same leaf
     uint32_t pad;
@@ -55,6 +60,7 @@ struct PackedBVH {
     std::vector<PackedNode> nodes;
     std::vector<PackedTri> tris;
     uint32_t root_ref = REF_EMPTY_LEAF;
+    uint32_t dummy_tri = 0;         // index of the degenerate record (A=B=C=0, never hit) empty leaves point at
     int max_depth = 0;              // levels, root = 1
     bool bounds_finite = true;      // no NaN / Inf in any child box
 };

@@ -31,6 +31,7 @@ struct ptmi_ctx {
     float4 *d_tris = nullptr;
     uint32_t root_ref = ptmi::D_REF_EMPTY_LEAF;
     uint32_t bounds_finite = 0;
+    uint32_t dummy_tri = 0;
     std::vector<float> verts;          // kept for the scene upload (emissive sampling, normals)
     std::vector<uint32_t> tri_idx;
 
@@ -42,17 +43,18 @@ struct ptmi_ctx {
     // scene + wavefront integrator state (ptmi_render.hip)
     struct RenderState *render = nullptr;
 
-    // extend kernel selection (0 = if-if one-shot, 1 = while-while + fast slab, 2 = persistent with ray refill)
-    int extend_variant = 0;
-    int persist_waves_per_cu = 16;
-    int persist_refill_below = 40;      // refill a wave's idle lanes once fewer than this many are active
+    // extend kernel selection and tuning (1 = persistent vote-scheduled kernel, 0 = one-shot if-if kernel)
+    int extend_variant = 1;
+    int persist_waves_per_cu = 32;      // upper bound; the launch takes min(this, what the LDS stacks allow)
     int num_cus = 256;
+    int vote_refill_min = 16;           // refill once this many lanes are idle
+    int vote_tri_bias = -8;             // inner step wins the vote when nI + bias >= nT
 
     // work counters
     bool counting = false;
     unsigned long long *d_counters = nullptr;
 
-    ptmi::DevBVH dev_bvh() const { return ptmi::DevBVH{d_nodes, d_tris, root_ref, bounds_finite}; }
+    ptmi::DevBVH dev_bvh() const { return ptmi::DevBVH{d_nodes, d_tris, root_ref, bounds_finite, dummy_tri}; }
 };
 
 namespace ptmi {

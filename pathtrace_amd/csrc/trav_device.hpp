@@ -20,7 +20,14 @@ struct DevBVH {
     const float4 *tris;    // 3 x float4 per packed triangle
     uint32_t root_ref;
     uint32_t bounds_finite;   // every child box of every packed node is finite (enables slab_fast)
+    uint32_t dummy_tri;       // record empty leaves point at (degenerate, never hit); only the counters care
 };
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Packed node quarters: q0 = c0min.x c0max.x c1min.x c1max.x | q1 = same for y | q2 = same for z |
+// q3 = ref0 ref1 - -.  Child k's box is (q0[2k], q1[2k], q2[2k]) - (q0[2k+1], q1[2k+1], q2[2k+1]).
+// Packed triangle: r0 = B.x C.x B.y C.y | r1 = B.z C.z A.x A.y | r2 = A.z prim nleft -.
 
 // Go builtin max/min (NaN if either operand is NaN).  The sign of a zero result is not
 // reproduced: slab distances are only ever compared, never output.
@@ -123,9 +130,8 @@ __device__ __forceinline__ void closest_hit(const DevBVH &bvh, uint32_t *stack_b
             if (COUNT) cnt.inner++;
             const float4 *p = bvh.nodes + (size_t)cur * 4;
             const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-            // q0 = c0min.xyz c0max.x | q1 = c0max.yz c1min.xy | q2 = c1min.z c1max.xyz | q3 = ref0 ref1 - -
-            float d1 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, best_t);
-            float d2 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, best_t);
+            float d1 = slab(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, best_t);
+            float d2 = slab(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, best_t);
             uint32_t i = __float_as_uint(q3.x), j = __float_as_uint(q3.y);
             if (d1 > d2) { uint32_t ti = i; i = j; j = ti; float td = d1; d1 = d2; d2 = td; }   // :148-151
             if (d1 == PT_INF) {                                                                  // :152-154
@@ -137,22 +143,20 @@ __device__ __forceinline__ void closest_hit(const DevBVH &bvh, uint32_t *stack_b
             cur = i;                                                                             // :160 (pushed, popped next)
             continue;
         }
-        if (cur != D_REF_EMPTY_LEAF) {
+        {
             if (COUNT) cnt.leaf++;
-            const float4 *p = bvh.tris + (size_t)(cur & 0x7FFFFFFFu) * 3;
+            const uint32_t first = cur & 0x7FFFFFFFu;
+            const float4 *p = bvh.tris + (size_t)first * 3;
             for (;;) {
                 const float4 r0 = p[0], r1 = p[1], r2 = p[2];
-                // r0 = A.xyz B.x | r1 = B.yz C.xy | r2 = C.z prim nleft pad
-                if (COUNT) cnt.tri++;
+                if (COUNT && first != bvh.dummy_tri) cnt.tri++;
                 float t;
-                bool hit = segment_triangle(ox, oy, oz, dx, dy, dz, best_t, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y,
-                                            r1.z, r1.w, r2.x, t);
+                bool hit = segment_triangle(ox, oy, oz, dx, dy, dz, best_t, r1.z, r1.w, r2.x, r0.x, r0.z, r1.x,
+                                            r0.y, r0.w, r1.y, t);
                 if (hit && t < best_t && t > 0.0f) { best_t = t; best = (int)__float_as_uint(r2.y); }   // :133-136
                 if (__float_as_uint(r2.z) == 0u) break;
                 p += 3;
             }
-        } else if (COUNT) {
-            cnt.leaf++;
         }
         if (st.empty()) break;
         cur = st.pop();
@@ -161,7 +165,7 @@ __device__ __forceinline__ void closest_hit(const DevBVH &bvh, uint32_t *stack_b
     t_out = best >= 0 ? best_t : 0.0f;
 }
 
-// ---- step-wise form of the same walk (used by the persistent / refilling kernels) -------------------
+// ---- step-wise form of the same walk (used by the persistent kernel) --------------------------------
 //
 // slab_fast: linear_bvh.go:23-70 for rays whose slab products cannot be NaN.  A product (bound - o) * inv
 // is NaN only for 0*inf, inf*0 or NaN inputs; with finite bounds (checked at upload), finite origin, finite
@@ -178,6 +182,14 @@ __device__ __forceinline__ float slab_fast(float minx, float miny, float minz, f
     lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2));
     const bool miss = lo > fminf(hi, step) || hi < 0.0f;
     return miss ? PT_INF : fmaxf(0.0f, lo);
+}
+
+// Both children of a packed node at once.  (Packed-f32 forms of the twelve products were measured: on
+// gfx950 v_pk_mul_f32 issues at half the rate of v_mul_f32, so they buy nothing -- tools/ubench_pk.hip.)
+__device__ __forceinline__ void slab_fast2(const float4 q0, const float4 q1, const float4 q2, float ox, float oy,
+                                           float oz, float ix, float iy, float iz, float step, float &d1, float &d2) {
+    d1 = slab_fast(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, step);
+    d2 = slab_fast(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, step);
 }
 
 constexpr uint32_t D_REF_DONE = 0xFFFFFFFEu;     // traversal finished (has the leaf bit, never a real leaf)
@@ -202,73 +214,87 @@ __device__ __forceinline__ void trav_init(RayTrav &r, const DevBVH &bvh, float o
                 finitef(step)) || !bvh.bounds_finite;
 }
 
-// one inner node of CheckIntersection (linear_bvh.go:138-162); r.cur must be an inner reference
+// ---- single-step forms for the vote-scheduled kernel -------------------------------------------------
+//
+// A lane is in one of three states, encoded in r.cur: at an inner node (leaf bit clear), at a triangle
+// record (leaf bit set; low bits = record index, advanced one record per step) or DONE.  Each wave
+// iteration runs ONE step type for the lanes in that state, chosen by majority, so no lane waits for a
+// neighbour's whole leaf or whole descent.  Both steps are branch-free apart from the LDS stack access.
+
+// pop the next reference (or DONE) -- linear_bvh.go:124-126
+template <int BLOCK>
+__device__ __forceinline__ uint32_t trav_pop(uint32_t *stack_base, int &sp) {
+    if (sp == 0) return D_REF_DONE;
+    --sp;
+    return stack_base[sp * BLOCK];
+}
+
+// linear_bvh.go:138-162 for one inner node; r.cur must be an inner reference
 template <int BLOCK, bool COUNT, bool EXACT>
-__device__ __forceinline__ void inner_step(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
+__device__ __forceinline__ void vote_inner_step(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
     if (COUNT) cnt.inner++;
     const float4 *p = bvh.nodes + (size_t)r.cur * 4;
     const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
     float d1, d2;
     if (EXACT) {
-        d1 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.best_t);
-        d2 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.best_t);
+        d1 = slab(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.best_t);
+        d2 = slab(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.best_t);
     } else {
-        d1 = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.best_t);
-        d2 = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.best_t);
+        slab_fast2(q0, q1, q2, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.best_t, d1, d2);
     }
-    uint32_t i = __float_as_uint(q3.x), j = __float_as_uint(q3.y);
-    if (d1 > d2) { uint32_t ti = i; i = j; j = ti; float td = d1; d1 = d2; d2 = td; }   // :148-151
-    if (d1 == PT_INF) {                                                                  // :152-154
-        if (r.sp == 0) { r.cur = D_REF_DONE; return; }
-        --r.sp; r.cur = stack_base[r.sp * BLOCK];
-        return;
+    const uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
+    const bool sw = d1 > d2;                                        // :148-151
+    const uint32_t near = sw ? r1 : r0, far = sw ? r0 : r1;
+    const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
+    if (dn == PT_INF) {                                             // :152-154
+        r.cur = trav_pop<BLOCK>(stack_base, r.sp);
+    } else {
+        if (df < r.best_t) { stack_base[r.sp * BLOCK] = far; ++r.sp; }   // :156-159
+        r.cur = near;                                               // :160
     }
-    if (d2 < r.best_t) { stack_base[r.sp * BLOCK] = j; ++r.sp; }                         // :156-159
-    r.cur = i;                                                                           // :160
 }
 
-// one leaf of CheckIntersection (linear_bvh.go:129-137), then pop; r.cur must be a leaf reference (not DONE)
+// One triangle of a leaf (linear_bvh.go:129-137 + utils.go:63-125), all four dot products and both cross
+// products evaluated as packed-f32 pairs.  Every packed lane is the same single IEEE operation as the
+// scalar source line, in the same association order, so results are bit-identical; the early returns of
+// utils.go become one predicate (a NaN fails each `<`/`>` exactly as in the reference).
 template <int BLOCK, bool COUNT>
-__device__ __forceinline__ void leaf_step(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
-    if (COUNT) cnt.leaf++;
-    if (r.cur != D_REF_EMPTY_LEAF) {
-        const float4 *p = bvh.tris + (size_t)(r.cur & 0x7FFFFFFFu) * 3;
-        for (;;) {
-            const float4 r0 = p[0], r1 = p[1], r2 = p[2];
-            if (COUNT) cnt.tri++;
-            float t;
-            bool hit = segment_triangle(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.best_t, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y,
-                                        r1.z, r1.w, r2.x, t);
-            if (hit && t < r.best_t && t > 0.0f) { r.best_t = t; r.best = (int)__float_as_uint(r2.y); }   // :133-136
-            if (__float_as_uint(r2.z) == 0u) break;
-            p += 3;
-        }
-    }
-    if (r.sp == 0) { r.cur = D_REF_DONE; return; }
-    --r.sp; r.cur = stack_base[r.sp * BLOCK];
-}
-
-// CheckIntersection, while-while form over the steps above; the wave takes the exact slab only when one
-// of its rays needs it.
-template <int BLOCK, bool COUNT>
-__device__ __forceinline__ void closest_hit_ww(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
-                                               float dx, float dy, float dz, float step, int &prim_out, float &t_out,
-                                               TravCounters &cnt) {
-    RayTrav r;
-    trav_init(r, bvh, ox, oy, oz, dx, dy, dz, step);
-    if (__any(r.exact)) {
-        while (r.cur != D_REF_DONE) {
-            while (!(r.cur & D_REF_LEAF_BIT)) inner_step<BLOCK, COUNT, true>(bvh, stack_base, r, cnt);
-            if (r.cur != D_REF_DONE) leaf_step<BLOCK, COUNT>(bvh, stack_base, r, cnt);
-        }
+__device__ __forceinline__ void vote_tri_step(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
+    const float EPS = (float)1e-6;
+    const float ONE_PLUS_EPS = (float)1.000001;
+    const uint32_t rec = r.cur & 0x7FFFFFFFu;
+    const float4 *p = bvh.tris + (size_t)rec * 3;
+    const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+    const float ax = r1.z, ay = r1.w, az = r2.x;
+    const f2 ex = f2{r0.x, r0.y} - f2{ax, ax};          // (edge1.x, edge2.x)   utils.go:70-71
+    const f2 ey = f2{r0.z, r0.w} - f2{ay, ay};
+    const f2 ez = f2{r1.x, r1.y} - f2{az, az};
+    const f2 vx = {r.ox - ax, r.dx};                    // (tvec.x, dir.x)      utils.go:91
+    const f2 vy = {r.oy - ay, r.dy};
+    const f2 vz = {r.oz - az, r.dz};
+    // (qvec, pvec) = (tvec x edge1, dir x edge2)        utils.go:103-107, :77-81
+    const f2 cx = vy * ez - vz * ey;
+    const f2 cy = vz * ex - vx * ez;
+    const f2 cz = vx * ey - vy * ex;
+    const f2 sx = __builtin_shufflevector(cx, cx, 1, 0), sy = __builtin_shufflevector(cy, cy, 1, 0),
+             sz = __builtin_shufflevector(cz, cz, 1, 0);            // (pvec, qvec)
+    const f2 m = (ex * sx + ey * sy) + ez * sz;         // (det = edge1.pvec, edge2.qvec)   utils.go:83, :116
+    const f2 k = (vx * sx + vy * sy) + vz * sz;         // (tvec.pvec, dir.qvec)            utils.go:93, :108
+    const float det = m.x;
+    const float inv = 1.0f / det;                       // utils.go:88
+    const float u = k.x * inv, v = k.y * inv, t = m.y * inv;
+    bool hit = !(fabsf(det) < EPS);                                          // :84-86
+    hit = hit && !(u < -EPS || u > ONE_PLUS_EPS);                            // :96-98
+    hit = hit && !(v < -EPS || u + v > ONE_PLUS_EPS);                        // :111-113
+    hit = hit && !(t <= EPS || t > r.best_t);                                // :118-120 (stepSize = best_t, linear_bvh.go:132)
+    if (COUNT) { if (rec != bvh.dummy_tri) cnt.tri++; }
+    if (hit && t < r.best_t && t > 0.0f) { r.best_t = t; r.best = (int)__float_as_uint(r2.y); }   // linear_bvh.go:133-136
+    if (__float_as_uint(r2.z) == 0u) {                  // last record of the leaf
+        if (COUNT) cnt.leaf++;
+        r.cur = trav_pop<BLOCK>(stack_base, r.sp);
     } else {
-        while (r.cur != D_REF_DONE) {
-            while (!(r.cur & D_REF_LEAF_BIT)) inner_step<BLOCK, COUNT, false>(bvh, stack_base, r, cnt);
-            if (r.cur != D_REF_DONE) leaf_step<BLOCK, COUNT>(bvh, stack_base, r, cnt);
-        }
+        r.cur = r.cur + 1u;
     }
-    prim_out = r.best;
-    t_out = r.best >= 0 ? r.best_t : 0.0f;
 }
 
 // QuickCheckIntersection (linear_bvh.go:202-250)
@@ -283,8 +309,8 @@ __device__ __forceinline__ bool any_hit(const DevBVH &bvh, uint32_t *stack_base,
             if (COUNT) cnt.inner++;
             const float4 *p = bvh.nodes + (size_t)cur * 4;
             const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-            float d1 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, step);
-            float d2 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, step);
+            float d1 = slab(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, step);
+            float d2 = slab(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, step);
             uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
             bool h1 = d1 < step, h2 = d2 < step;
             if (h1 && h2) {                              // :226-238 push far first, near on top
@@ -296,20 +322,19 @@ __device__ __forceinline__ bool any_hit(const DevBVH &bvh, uint32_t *stack_base,
             cur = st.pop();
             continue;
         }
-        if (cur != D_REF_EMPTY_LEAF) {
+        {
             if (COUNT) cnt.leaf++;
-            const float4 *p = bvh.tris + (size_t)(cur & 0x7FFFFFFFu) * 3;
+            const uint32_t first = cur & 0x7FFFFFFFu;
+            const float4 *p = bvh.tris + (size_t)first * 3;
             for (;;) {
                 const float4 r0 = p[0], r1 = p[1], r2 = p[2];
-                if (COUNT) cnt.tri++;
-                if (shadow_triangle(ox, oy, oz, dx, dy, dz, step, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w,
-                                    r2.x))
+                if (COUNT && first != bvh.dummy_tri) cnt.tri++;
+                if (shadow_triangle(ox, oy, oz, dx, dy, dz, step, r1.z, r1.w, r2.x, r0.x, r0.z, r1.x, r0.y, r0.w,
+                                    r1.y))
                     return true;
                 if (__float_as_uint(r2.z) == 0u) break;
                 p += 3;
             }
-        } else if (COUNT) {
-            cnt.leaf++;
         }
         if (st.empty()) return false;
         cur = st.pop();
