@@ -13,7 +13,8 @@
 enum {
     CNT_CLOSEST = 0, CNT_ANY = 1, CNT_INNER = 2, CNT_TRI = 3, CNT_LEAF = 4, CNT_DIFFUSE = 5, CNT_SAMPLES = 6,
     CNT_NEXT_RAY = 7,      // ray cursor of the persistent extend kernel (reset before each launch)
-    CNT_WORDS = 8
+    CNT_ERROR = 8,         // bit set of integrator self-check failures (ptmi_render.hip: ERR_*), must stay 0
+    CNT_WORDS = 16
 };
 
 struct ptmi_ctx {

@@ -28,12 +28,15 @@ namespace {
 constexpr int WAVE = 64;
 
 // ---- frame fields (one frame per TraceRay invocation on the explicit recursion stack) ----------
+// A frame is 32 words = one 128-byte line, stored per path ([slot][depth][32]): shade loads the top
+// frame with eight 16-byte loads into registers, works on it there and writes it back when the path
+// parks (queue order is arbitrary, so a [field][slot] layout costs one 32/64-byte sector per word).
 enum {
     F_BOUNCES = 0, F_BINDEX = 1, F_FLAGS = 2, F_ENERGY = 3, F_LN = 4,      // inputs of TraceRay (:15)
     F_RO = 7, F_RD = 10, F_T = 13, F_PRIM = 14,                            // the hit being shaded
     F_DG = 15, F_DIFF = 16,                                                // doppler*gravity, diffuse component
     F_REFR = 19, F_DIRECT = 22, F_SUM = 25, F_S = 28, F_PHASE = 29, F_NEED = 30,
-    NF = 31
+    NF = 31, FRW = 32
 };
 enum { FL_SPECULAR = 1, FL_FLIPPED = 2 };
 // what the top frame is waiting for
@@ -41,9 +44,16 @@ enum { PH_EXTEND = 0, PH_REFR_WAIT = 1, PH_SHADOW_WAIT = 2, PH_GI_WAIT = 3, PH_R
 enum { HS_MISS = 0, HS_HIT = 1, HS_HORIZON = 2 };
 // queue counters
 enum { Q_EXT = 0, Q_SHADOW_PATHS = 1, Q_SHADOW_RAYS = 2, Q_FREE = 3, Q_WORDS = 8 };
+// path header, 16 words = 64 bytes per slot
+enum { H_SID = 0, H_KEY = 1, H_CTR = 2, H_DEPTH = 3, H_TRKLEN = 4, H_HSTATUS = 5, H_HPRIM = 6, H_HT = 7,
+       H_VT0 = 8, H_VT1 = 9, H_RO = 10, H_RD = 13, HDRW = 16 };
+
+// self-check failures reported through counters[CNT_ERROR] (a corrupted path is dropped, never dereferenced)
+enum { ERR_SLOT = 1, ERR_DEPTH = 2, ERR_PRIM = 4, ERR_MAT = 8, ERR_PHASE = 16 };
 
 struct DevScene {
-    const float *verts; const uint32_t *tri_idx; const float *normals; const uint32_t *tri_mat;
+    const float4 *stri;                  // shading record per triangle, 5 x float4: A B C, N0 N1 N2, material id
+    uint32_t ntris, nmats;
     const PtMaterial *mats; const uint32_t *emissive; uint32_t nemissive;
     const PtLight *lights; uint32_t nlights;
     PtSky sky; const uint16_t *sky_img;
@@ -58,22 +68,19 @@ struct RenderArgs {
     uint64_t total;                      // w*h*spp_chunk
 };
 
-// Path pool, SoA.  All arrays have `cap` slots.
+// Path pool: array of structures per slot.
 struct Pool {
     uint32_t cap;
-    int nframes, ntrk, nshadow;          // bounces+1, tracker history capacity, nlights+2
-    uint32_t *sid, *rng_key, *rng_ctr;
-    int32_t *depth;
-    uint32_t *trk_len; float *trk;       // [ntrk][cap]
-    float *ro, *rd;                      // [3][cap] current ray (updated by extend while marching)
-    int32_t *hstatus, *hprim; float *ht, *vt0, *vt1;
-    float *fr;                           // [nframes*NF][cap]
-    float *sh_contrib;                   // [nshadow*3][cap]
-    uint8_t *sh_occ;                     // [nshadow][cap]
+    int nframes, ntrk, nshadow;          // bounces+1, tracker history capacity (multiple of 4), nlights+2
+    float4 *hdr;                         // [cap][4]            header (H_*)
+    float4 *fr;                          // [cap][nframes][8]   frames (F_*)
+    float *trk;                          // [cap][ntrk]         RefractiveIndexTracker.indices
+    float4 *sh;                          // [cap][nshadow]      (contribution.xyz, occluded as u32 bits)
+    float4 *park;                        // [cap][nshadow][2]   a path's shadow rays until the queue reservation
     // queues
     uint32_t *q_ext[2];                  // extend queue (double buffered)
     uint32_t *q_shpath[2];               // paths waiting for their shadow rays
-    float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, bits(target))
+    float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, bits(index into sh))
     uint32_t *q_free;                    // slots that finished in the last shade pass
     unsigned long long *qcnt;            // Q_WORDS counters
     float *out;                          // per-sample radiance [total][3]
@@ -92,6 +99,11 @@ __device__ __forceinline__ uint32_t wave_append(unsigned long long *counter, boo
     uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     return (uint32_t)base + prefix;
 }
+
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ float i2f(int32_t i) { return __int_as_float(i); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ int32_t f2i(float f) { return __float_as_int(f); }
 
 // ------------------------------------------------------------------------------------------ generate
 // main.go:861-874 + the TraceRay call of :875 (bounceIndex 0, lastSurfaceNormal {}, not specular,
@@ -114,20 +126,16 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, c
         V3 pos = mk(ra.cam.position), fwd = mk(ra.cam.forward), right = mk(ra.cam.right), up = mk(ra.cam.up);
         V3 rayOrigin = add(add(add(pos, scale(fwd, ra.cam.frustum_distance)), scale(up, py)), scale(right, px));
         V3 d = normalize(mk(rayOrigin.x - pos.x, rayOrigin.y - pos.y, rayOrigin.z - pos.z));
-        const uint32_t cap = pl.cap;
-        pl.sid[slot] = (uint32_t)sid;
-        pl.rng_key[slot] = rng.key; pl.rng_ctr[slot] = rng.ctr;
-        pl.depth[slot] = 0;
-        pl.trk_len[slot] = 1; pl.trk[slot] = 1.0f;
-        pl.ro[slot] = pos.x; pl.ro[cap + slot] = pos.y; pl.ro[2 * cap + slot] = pos.z;
-        pl.rd[slot] = d.x; pl.rd[cap + slot] = d.y; pl.rd[2 * cap + slot] = d.z;
-        float *f = pl.fr + slot;
-        ((int32_t *)f)[(size_t)F_BOUNCES * cap] = ra.p.bounces;
-        ((int32_t *)f)[(size_t)F_BINDEX * cap] = 0;
-        ((uint32_t *)f)[(size_t)F_FLAGS * cap] = 0u;
-        f[(size_t)F_ENERGY * cap] = 1.0f;
-        f[(size_t)(F_LN + 0) * cap] = 0.0f; f[(size_t)(F_LN + 1) * cap] = 0.0f; f[(size_t)(F_LN + 2) * cap] = 0.0f;
-        ((uint32_t *)f)[(size_t)F_PHASE * cap] = PH_EXTEND;
+        float4 *h = pl.hdr + (size_t)slot * 4;
+        h[0] = make_float4(u2f((uint32_t)sid), u2f(rng.key), u2f(rng.ctr), i2f(0));
+        h[1] = make_float4(u2f(1u), i2f(HS_MISS), i2f(-1), 0.0f);
+        h[2] = make_float4(1.0f, 1.0f, pos.x, pos.y);
+        h[3] = make_float4(pos.z, d.x, d.y, d.z);
+        pl.trk[(size_t)slot * pl.ntrk] = 1.0f;
+        float4 *f = pl.fr + (size_t)slot * pl.nframes * 8;
+        f[0] = make_float4(i2f(ra.p.bounces), i2f(0), u2f(0u), 1.0f);
+        f[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        ((uint32_t *)f)[F_PHASE] = PH_EXTEND;
     }
     // TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0; shade handles that case
     uint32_t pos_q = wave_append(qcnt_next_ext, live);
@@ -145,9 +153,12 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
     uint32_t i = blockIdx.x * WAVE + threadIdx.x;
     uint32_t nq = 0;
     if (i < n) {
-        const uint32_t slot = queue[i], cap = pl.cap;
-        V3 o = mk(pl.ro[slot], pl.ro[cap + slot], pl.ro[2 * cap + slot]);
-        V3 d = mk(pl.rd[slot], pl.rd[cap + slot], pl.rd[2 * cap + slot]);
+        uint32_t slot = queue[i];
+        if (slot >= pl.cap) { atomicOr(&counters[CNT_ERROR], (unsigned long long)ERR_SLOT); slot = 0; }
+        float4 *hd = pl.hdr + (size_t)slot * 4;
+        const float4 h1 = hd[1], h2 = hd[2], h3 = hd[3];
+        V3 o = mk(h2.z, h2.w, h3.x);
+        V3 d = mk(h3.y, h3.z, h3.w);
         const bool curved = sc.has_bh != 0;
         RayState st = {0, 0, 0, 0, 0, 0, 0, 0};
         float vt0 = 1.0f;
@@ -169,10 +180,9 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
                 if (dot(rel, rel) <= sc.bh.rs * sc.bh.rs) { status = HS_HORIZON; break; }   // :250-255
             }
         }
-        pl.ro[slot] = o.x; pl.ro[cap + slot] = o.y; pl.ro[2 * cap + slot] = o.z;
-        pl.rd[slot] = d.x; pl.rd[cap + slot] = d.y; pl.rd[2 * cap + slot] = d.z;
-        pl.hstatus[slot] = status; pl.hprim[slot] = prim; pl.ht[slot] = t;
-        pl.vt0[slot] = vt0; pl.vt1[slot] = st.vt;
+        hd[1] = make_float4(h1.x, i2f(status), i2f(prim), t);
+        hd[2] = make_float4(vt0, st.vt, o.x, o.y);
+        hd[3] = make_float4(o.z, d.x, d.y, d.z);
     }
     for (int off = 32; off > 0; off >>= 1) nq += __shfl_xor(nq, off);
     if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&counters[CNT_CLOSEST], (unsigned long long)nq);
@@ -188,7 +198,9 @@ __global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool p
         const float4 a = pl.q_sray_a[i], b = pl.q_sray_b[i];
         TravCounters tc;
         bool occ = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, b.x, b.y, b.z, a.w, tc);
-        pl.sh_occ[__float_as_uint(b.w)] = occ ? 1 : 0;
+        const uint32_t target = f2u(b.w);
+        if (target < pl.cap * (uint32_t)pl.nshadow) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = occ ? 1u : 0u;
+        else atomicOr(&counters[CNT_ERROR], (unsigned long long)ERR_SLOT);
     }
     if (threadIdx.x == 0) {
         uint32_t cnt = min((uint32_t)WAVE, n - blockIdx.x * WAVE);
@@ -204,8 +216,16 @@ struct Hit {            // a frame's hit, re-derived from the frame's stored ray
     uint32_t mat;
 };
 
-__device__ __forceinline__ V3 vert(const DevScene &sc, uint32_t vi) { return mk(sc.verts + 3 * (size_t)vi); }
-__device__ __forceinline__ V3 nrm(const DevScene &sc, size_t ci) { return mk(sc.normals + 3 * ci); }
+struct STri { V3 A, B, C, N0, N1, N2; uint32_t mat; };
+__device__ __forceinline__ STri load_stri(const DevScene &sc, uint32_t prim) {
+    const float4 *p = sc.stri + (size_t)prim * 5;
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+    STri t;
+    t.A = mk(q0.x, q0.y, q0.z); t.B = mk(q0.w, q1.x, q1.y); t.C = mk(q1.z, q1.w, q2.x);
+    t.N0 = mk(q2.y, q2.z, q2.w); t.N1 = mk(q3.x, q3.y, q3.z); t.N2 = mk(q3.w, q4.x, q4.y);
+    t.mat = f2u(q4.z);
+    return t;
+}
 __device__ __forceinline__ bool is_emissive(const PtMaterial &m) { return m.ke[0] > 0.0f || m.ke[1] > 0.0f || m.ke[2] > 0.0f; }
 
 // States of the per-path machine inside one shade invocation.
@@ -215,79 +235,112 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                                                     uint32_t na, const uint32_t *list_b, uint32_t nb,
                                                     uint32_t *q_ext_next, uint32_t *q_shpath_next,
                                                     unsigned long long *counters) {
+    __shared__ float s_fw[FRW * 256];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < na + nb;
-    const uint32_t cap = pl.cap;
     uint32_t slot = 0;
     bool want_extend = false, want_shadow = false, finished = false;
     uint32_t n_sray = 0;                       // shadow rays this path wants to enqueue
+    uint32_t need_out = 0;                     // their slots (bit k = shadow slot k)
     uint32_t diffuse_events = 0;
-    // shadow rays are staged in registers until the wave-wide queue reservation below
-    // (at most nshadow per path; written to the queue after the loop)
     if (live) {
         slot = i < na ? list_a[i] : list_b[i - na];
-        int depth = pl.depth[slot];
-        Rng rng; rng.key = pl.rng_key[slot]; rng.ctr = pl.rng_ctr[slot];
-        uint32_t trk_len = pl.trk_len[slot];
-#define FRF(dep, field) pl.fr[((size_t)(dep) * NF + (field)) * cap + slot]
-#define FRI(dep, field) (((int32_t *)pl.fr)[((size_t)(dep) * NF + (field)) * cap + slot])
-#define FRU(dep, field) (((uint32_t *)pl.fr)[((size_t)(dep) * NF + (field)) * cap + slot])
-#define FRV(dep, field) mk(FRF(dep, (field)), FRF(dep, (field) + 1), FRF(dep, (field) + 2))
-#define FRV_SET(dep, field, v) do { V3 v__ = (v); FRF(dep, (field)) = v__.x; FRF(dep, (field) + 1) = v__.y; FRF(dep, (field) + 2) = v__.z; } while (0)
-#define TRK(k) pl.trk[(size_t)(k) * cap + slot]
-        auto trk_current = [&]() -> float { return trk_len == 0 ? 1.0f : TRK(trk_len - 1); };
-        auto trk_previous = [&]() -> float { return trk_len < 2 ? 1.0f : TRK(trk_len - 2); };
+        uint32_t err = 0;
+        if (slot >= pl.cap) { err = ERR_SLOT; slot = 0; }
+        float4 *hd = pl.hdr + (size_t)slot * 4;
+        const float4 h0 = hd[0], h1 = hd[1], h2 = hd[2], h3 = hd[3];
+        const uint32_t sid = f2u(h0.x);
+        Rng rng; rng.key = f2u(h0.y); rng.ctr = f2u(h0.z);
+        int depth = f2i(h0.w);
+        if (depth < 0 || depth >= pl.nframes) { err |= ERR_DEPTH; depth = 0; }
+        uint32_t trk_len = f2u(h1.x);
+        const int hs = f2i(h1.y), hprim = f2i(h1.z);
+        const float ht = h1.w, vt0 = h2.x, vt1 = h2.y;
+        V3 cur_o = mk(h2.z, h2.w, h3.x), cur_d = mk(h3.y, h3.z, h3.w);      // the path's current ray
+        float *trk = pl.trk + (size_t)slot * pl.ntrk;
+        float4 *frames = pl.fr + (size_t)slot * pl.nframes * 8;
+        float4 *shp = pl.sh + (size_t)slot * pl.nshadow;
+        float4 *park = pl.park + (size_t)slot * pl.nshadow * 2;
 
-        // (re)derive the hit of frame `dep` from what the frame stores
-        auto load_hit = [&](int dep, Hit &h) {
-            h.ro = FRV(dep, F_RO); h.rd = FRV(dep, F_RD);
-            h.prim = FRI(dep, F_PRIM);
-            float t = FRF(dep, F_T);
-            h.P = add(h.ro, scale(h.rd, t));                                        // tracer.go:37
-            const uint32_t *ix = sc.tri_idx + 3 * (size_t)h.prim;
-            h.A = vert(sc, ix[0]); h.B = vert(sc, ix[1]); h.C = vert(sc, ix[2]);
-            V3 n = normalize(interpolate_normal(h.P, h.A, h.B, h.C, nrm(sc, 3 * (size_t)h.prim),
-                                                nrm(sc, 3 * (size_t)h.prim + 1), nrm(sc, 3 * (size_t)h.prim + 2)));   // :38-46
-            if (FRU(dep, F_FLAGS) & FL_FLIPPED) n = scale(n, -1.0f);                // :53
-            h.normal = n;
-            h.mat = sc.tri_mat[h.prim];
+        // The top frame lives in LDS, [word][thread] (conflict-free): it is read and written all over the state
+        // machine below, and 32 more loop-carried registers per lane are what this kernel cannot afford.
+        const uint32_t tid = threadIdx.x;
+#define FW(field) s_fw[(field) * 256 + tid]
+        auto load_frame = [&](int dep) {
+            const float4 *f = frames + (size_t)dep * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float4 v = f[k]; FW(4 * k) = v.x; FW(4 * k + 1) = v.y; FW(4 * k + 2) = v.z; FW(4 * k + 3) = v.w; }
         };
-        // push a child TraceRay invocation and request its extend
+        auto store_frame = [&](int dep) {
+            float4 *f = frames + (size_t)dep * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = make_float4(FW(4 * k), FW(4 * k + 1), FW(4 * k + 2), FW(4 * k + 3));
+        };
+#define FV(field) mk(FW(field), FW((field) + 1), FW((field) + 2))
+#define FV_SET(field, v) do { V3 v__ = (v); FW(field) = v__.x; FW((field) + 1) = v__.y; FW((field) + 2) = v__.z; } while (0)
+#define FI(field) f2i(FW(field))
+#define FU(field) f2u(FW(field))
+#define FI_SET(field, v) (FW(field) = i2f(v))
+#define FU_SET(field, v) (FW(field) = u2f(v))
+        auto trk_current = [&]() -> float { return trk_len == 0 ? 1.0f : trk[trk_len - 1]; };
+        auto trk_previous = [&]() -> float { return trk_len < 2 ? 1.0f : trk[trk_len - 2]; };
+
+        // (re)derive the hit of the top frame from what the frame stores
+        auto load_hit = [&](Hit &h) {
+            h.ro = FV(F_RO); h.rd = FV(F_RD);
+            h.prim = FI(F_PRIM);
+            if ((uint32_t)h.prim >= sc.ntris) { err |= ERR_PRIM; h.prim = 0; }
+            float t = FW(F_T);
+            h.P = add(h.ro, scale(h.rd, t));                                        // tracer.go:37
+            STri tr = load_stri(sc, (uint32_t)h.prim);
+            if (tr.mat >= sc.nmats) { err |= ERR_MAT; tr.mat = 0; }
+            h.A = tr.A; h.B = tr.B; h.C = tr.C;
+            V3 n = normalize(interpolate_normal(h.P, h.A, h.B, h.C, tr.N0, tr.N1, tr.N2));   // :38-46
+            if (FU(F_FLAGS) & FL_FLIPPED) n = scale(n, -1.0f);                      // :53
+            h.normal = n;
+            h.mat = tr.mat;
+        };
+        // park the top frame, push a child TraceRay invocation above it and request its extend
         auto push_child = [&](int dep, int bounces, int bindex, V3 lastN, bool specular, float energy, V3 o, V3 d) {
-            FRI(dep + 1, F_BOUNCES) = bounces; FRI(dep + 1, F_BINDEX) = bindex;
-            FRU(dep + 1, F_FLAGS) = specular ? FL_SPECULAR : 0u;
-            FRF(dep + 1, F_ENERGY) = energy; FRV_SET(dep + 1, F_LN, lastN);
-            FRU(dep + 1, F_PHASE) = PH_EXTEND;
-            pl.ro[slot] = o.x; pl.ro[cap + slot] = o.y; pl.ro[2 * cap + slot] = o.z;
-            pl.rd[slot] = d.x; pl.rd[cap + slot] = d.y; pl.rd[2 * cap + slot] = d.z;
+            store_frame(dep);
+            float4 *f = frames + (size_t)(dep + 1) * 8;
+            f[0] = make_float4(i2f(bounces), i2f(bindex), u2f(specular ? (uint32_t)FL_SPECULAR : 0u), energy);
+            f[1] = make_float4(lastN.x, lastN.y, lastN.z, 0.0f);
+            ((uint32_t *)f)[F_PHASE] = PH_EXTEND;
+            cur_o = o; cur_d = d;
         };
 
         int state;
         V3 ret = mk(0, 0, 0);
         Hit h;
         bool have_hit = false;
+        load_frame(depth);
         // entry: what was the top frame waiting for?
         {
-            uint32_t ph = FRU(depth, F_PHASE);
+            uint32_t ph = FU(F_PHASE);
             if (ph == PH_EXTEND) state = ST_EXTENDED;
-            else { load_hit(depth, h); have_hit = true; state = ST_SHADOW_DONE; }   // PH_SHADOW_WAIT
+            else if (ph == PH_SHADOW_WAIT) { load_hit(h); have_hit = true; state = ST_SHADOW_DONE; }
+            else { err |= ERR_PHASE; state = ST_RETURN; depth = 0; }
         }
         for (;;) {
+            if (err) {      // self-check failed: report, drop the path with zero radiance
+                atomicOr(&counters[CNT_ERROR], (unsigned long long)err);
+                float *o = pl.out + 3 * (size_t)(sid < ra.total ? sid : 0);
+                o[0] = o[1] = o[2] = 0.0f;
+                want_extend = want_shadow = false; n_sray = 0; finished = true; break;
+            }
             if (state == ST_EXTENDED) {
                 // TraceRay entry test (tracer.go:16) for the primary ray; children are tested before being pushed
-                if (FRI(depth, F_BOUNCES) < 0 || FRF(depth, F_ENERGY) < (float)1e-2) { ret = mk(0, 0, 0); state = ST_RETURN; continue; }
-                const int hs = pl.hstatus[slot];
-                V3 o = mk(pl.ro[slot], pl.ro[cap + slot], pl.ro[2 * cap + slot]);
-                V3 d = mk(pl.rd[slot], pl.rd[cap + slot], pl.rd[2 * cap + slot]);
+                if (FI(F_BOUNCES) < 0 || FW(F_ENERGY) < (float)1e-2) { ret = mk(0, 0, 0); state = ST_RETURN; continue; }
                 if (hs == HS_HORIZON) { ret = mk(0, 0, 0); state = ST_RETURN; continue; }           // :253-255
                 if (hs == HS_MISS) {                                                                // :260-263
-                    ret = sc.sky.kind == PTMI_SKY_NONE ? mk(0, 0, 0) : sky_sample(sc.sky, sc.sky_img, d);
+                    ret = sc.sky.kind == PTMI_SKY_NONE ? mk(0, 0, 0) : sky_sample(sc.sky, sc.sky_img, cur_d);
                     state = ST_RETURN; continue;
                 }
-                FRV_SET(depth, F_RO, o); FRV_SET(depth, F_RD, d);
-                FRF(depth, F_T) = pl.ht[slot]; FRI(depth, F_PRIM) = pl.hprim[slot];
-                FRU(depth, F_FLAGS) &= ~(uint32_t)FL_FLIPPED;
-                load_hit(depth, h); have_hit = true;
+                FV_SET(F_RO, cur_o); FV_SET(F_RD, cur_d);
+                FW(F_T) = ht; FI_SET(F_PRIM, hprim);
+                FU_SET(F_FLAGS, FU(F_FLAGS) & ~(uint32_t)FL_FLIPPED);
+                load_hit(h); have_hit = true;
                 const PtMaterial &m = sc.mats[h.mat];
                 // doppler / gravitational factors and the disk colour depend only on this hit (:93-113)
                 float dg = 1.0f;
@@ -298,55 +351,55 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                     V3 vel = scale(tang, (float)0.9999);
                     float vpar = dot(scale(h.rd, -1.0f), vel);
                     float doppler = sqrtf((1.0f + vpar) / (1.0f - vpar));
-                    float grav = pl.vt0[slot] / pl.vt1[slot];
+                    float grav = vt0 / vt1;
                     dg = doppler * grav;
                     if (sc.bh.has_disk) diff0 = disk_color(sc.bh, h.P);
                 }
-                FRF(depth, F_DG) = dg; FRV_SET(depth, F_DIFF, diff0);
-                FRV_SET(depth, F_REFR, mk(0, 0, 0));
+                FW(F_DG) = dg; FV_SET(F_DIFF, diff0);
+                FV_SET(F_REFR, mk(0, 0, 0));
                 if (m.flags & PTMI_MAT_GLASS) {                                                     // :49-91
                     float ri = m.ni;
                     bool goingOut = false;
                     if (dot(h.normal, h.rd) > 0.0f) {
                         h.normal = scale(h.normal, -1.0f); goingOut = true; ri = trk_previous();
-                        FRU(depth, F_FLAGS) |= FL_FLIPPED;
+                        FU_SET(F_FLAGS, FU(F_FLAGS) | FL_FLIPPED);
                     }
                     bool tir;
                     V3 rdir = get_refracted_ray(h.rd, h.normal, trk_current(), ri, tir);
                     V3 rorg = add(h.P, scale(rdir, (float)0.001));
-                    const int bounces = FRI(depth, F_BOUNCES), bindex = FRI(depth, F_BINDEX);
-                    const float energy = FRF(depth, F_ENERGY);
+                    const int bounces = FI(F_BOUNCES), bindex = FI(F_BINDEX);
+                    const float energy = FW(F_ENERGY);
                     int cbi = bindex + 1;
                     if (!tir) {
-                        if (goingOut) { if (trk_len > 0) trk_len--; } else if ((int)trk_len < pl.ntrk) { TRK(trk_len) = ri; trk_len++; }
+                        if (goingOut) { if (trk_len > 0) trk_len--; } else if ((int)trk_len < pl.ntrk) { trk[trk_len] = ri; trk_len++; }
                         cbi = bindex;
                     }
                     const float ce = energy * (float)0.95;
                     if (!(ce < (float)1e-2 || bounces - 1 < 0)) {
-                        FRU(depth, F_PHASE) = PH_REFR_WAIT;
-                        push_child(depth, bounces - 1, cbi, FRV(depth, F_LN), (FRU(depth, F_FLAGS) & FL_SPECULAR) != 0, ce, rorg, rdir);
+                        FU_SET(F_PHASE, PH_REFR_WAIT);
+                        push_child(depth, bounces - 1, cbi, FV(F_LN), (FU(F_FLAGS) & FL_SPECULAR) != 0, ce, rorg, rdir);
                         depth++; want_extend = true; break;
                     }
                     // the child returns Vec3{} at its entry test: refraction = {} * energy
-                    FRV_SET(depth, F_REFR, scale(mk(0, 0, 0), energy));
+                    FV_SET(F_REFR, scale(mk(0, 0, 0), energy));
                 }
                 state = ST_MATERIAL; continue;
             }
             if (state == ST_MATERIAL) {
-                if (!have_hit) { load_hit(depth, h); have_hit = true; }
+                if (!have_hit) { load_hit(h); have_hit = true; }
                 const PtMaterial &m = sc.mats[h.mat];
                 const float reflectivity = (m.ks[0] + m.ks[1] + m.ks[2]) / 3.0f;                    // :116
                 bool take_reflective;
                 if (reflectivity < (float)0.1) take_reflective = false;
                 else if (reflectivity < (float)0.9) take_reflective = rng_f32(rng) < reflectivity;  // :163
                 else take_reflective = true;
-                FRV_SET(depth, F_SUM, mk(0, 0, 0)); FRI(depth, F_S) = 0;
+                FV_SET(F_SUM, mk(0, 0, 0)); FI_SET(F_S, 0);
                 if (take_reflective) { state = ST_REFL_LOOP; continue; }
-                const int bindex = FRI(depth, F_BINDEX);
+                const int bindex = FI(F_BINDEX);
                 if (bindex > 0 && is_emissive(m)) {                                                 // :461-465
                     V3 dc = mk(m.ke);
-                    if (!(FRU(depth, F_FLAGS) & FL_SPECULAR)) {                                     // :143-158
-                        float pdf_brdf = dot(h.rd, FRV(depth, F_LN)) / PT_PI32;
+                    if (!(FU(F_FLAGS) & FL_SPECULAR)) {                                             // :143-158
+                        float pdf_brdf = dot(h.rd, FV(F_LN)) / PT_PI32;
                         float area = triangle_area(h.A, h.B, h.C);
                         float pdf_area = 1.0f / ((float)sc.nemissive * area);
                         float cosLight = gomaxf(0.0f, dot(h.rd, h.normal));
@@ -354,7 +407,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                         float pdf_sa = pdf_area * distance * distance / cosLight;
                         dc = scale(dc, mis_weight(pdf_brdf, pdf_sa));
                     }
-                    FRV_SET(depth, F_DIFF, dc);
+                    FV_SET(F_DIFF, dc);
                     state = ST_COMBINE; continue;
                 }
                 // direct lighting of HandleDiffuseMaterial (:523-618): draw in the reference's order, stage the
@@ -364,12 +417,10 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                 uint32_t need = 0;
                 auto stage = [&](int k, V3 o, V3 d, float range, V3 contrib) {
                     need |= 1u << k;
-                    pl.sh_contrib[(size_t)(3 * k) * cap + slot] = contrib.x;
-                    pl.sh_contrib[(size_t)(3 * k + 1) * cap + slot] = contrib.y;
-                    pl.sh_contrib[(size_t)(3 * k + 2) * cap + slot] = contrib.z;
-                    // ray parked in the path's own shadow slots; copied to the queue after the reservation
-                    pl.q_sray_a[(size_t)cap * pl.nshadow + (size_t)k * cap + slot] = make_float4(o.x, o.y, o.z, range);
-                    pl.q_sray_b[(size_t)cap * pl.nshadow + (size_t)k * cap + slot] = make_float4(d.x, d.y, d.z, 0.0f);
+                    shp[k] = make_float4(contrib.x, contrib.y, contrib.z, u2f(0u));
+                    // ray parked in the path's own slots; copied to the queue after the wave-wide reservation
+                    park[2 * k] = make_float4(o.x, o.y, o.z, range);
+                    park[2 * k + 1] = make_float4(d.x, d.y, d.z, 0.0f);
                     n_sray++;
                 };
                 if (sc.sky.kind != PTMI_SKY_NONE) {                                                 // :531-542
@@ -399,10 +450,11 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                     V3 eo = add(h.P, scale(h.normal, (float)0.01));
                     uint32_t choice = rng_intn(rng, sc.nemissive);
                     uint32_t et = sc.emissive[choice];
-                    const uint32_t *ix = sc.tri_idx + 3 * (size_t)et;
-                    V3 p0 = vert(sc, ix[0]), p1 = vert(sc, ix[1]), p2 = vert(sc, ix[2]);
-                    V3 lightPoint = sample_triangle_point(rng, p0, p1, p2);
-                    V3 lsn = interpolate_normal(lightPoint, p0, p1, p2, nrm(sc, 3 * (size_t)et), nrm(sc, 3 * (size_t)et + 1), nrm(sc, 3 * (size_t)et + 2));
+                    if (et >= sc.ntris) { err |= ERR_PRIM; et = 0; }
+                    STri e = load_stri(sc, et);
+                    if (e.mat >= sc.nmats) { err |= ERR_MAT; e.mat = 0; }
+                    V3 lightPoint = sample_triangle_point(rng, e.A, e.B, e.C);
+                    V3 lsn = interpolate_normal(lightPoint, e.A, e.B, e.C, e.N0, e.N1, e.N2);
                     V3 toLight = sub(lightPoint, eo);
                     float distance = length(toLight);
                     toLight = normalize(toLight);
@@ -412,140 +464,149 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                         float sndorl = -dot(toLight, lsn);
                         if (!(sndorl <= 0.0f)) {
                             float geometryTerm = ndotl * sndorl / (distance * distance);
-                            float pdf = triangle_area(p0, p1, p2);
+                            float pdf = triangle_area(e.A, e.B, e.C);
                             pdf = 1.0f / (pdf * (float)sc.nemissive);
                             float pdf_brdf = dot(h.normal, toLight) / PT_PI32;
                             float pdf_sa = pdf * (distance * distance) / sndorl;
                             float weight = mis_weight(pdf_sa, pdf_brdf);
-                            V3 le = mk(sc.mats[sc.tri_mat[et]].ke);
+                            V3 le = mk(sc.mats[e.mat].ke);
                             V3 brdf = scale(albedo, (float)(1.0 / 3.14159265358979323846));
                             ec = scale(cmul(le, brdf), geometryTerm * weight / pdf);
                         }
                         stage(1 + (int)sc.nlights, eo, toLight, distance - (float)0.01, ec);
                     }
                 }
-                FRU(depth, F_NEED) = need;
-                if (need) { FRU(depth, F_PHASE) = PH_SHADOW_WAIT; want_shadow = true; break; }
+                FU_SET(F_NEED, need);
+                if (need) { FU_SET(F_PHASE, PH_SHADOW_WAIT); store_frame(depth); need_out = need; want_shadow = true; break; }
                 state = ST_SHADOW_DONE; continue;
             }
             if (state == ST_SHADOW_DONE) {
-                if (!have_hit) { load_hit(depth, h); have_hit = true; }
+                if (!have_hit) { load_hit(h); have_hit = true; }
                 const PtMaterial &m = sc.mats[h.mat];
                 const V3 albedo = mk(m.kd);
-                const uint32_t need = FRU(depth, F_NEED);
-                auto lit = [&](int k) -> bool { return (need >> k & 1u) && pl.sh_occ[(size_t)k * cap + slot] == 0; };
-                auto contrib = [&](int k) -> V3 {
-                    return mk(pl.sh_contrib[(size_t)(3 * k) * cap + slot], pl.sh_contrib[(size_t)(3 * k + 1) * cap + slot],
-                              pl.sh_contrib[(size_t)(3 * k + 2) * cap + slot]);
-                };
+                const uint32_t need = FU(F_NEED);
                 V3 direct = mk(0, 0, 0);
-                if (sc.sky.kind != PTMI_SKY_NONE && lit(0)) direct = add(direct, contrib(0));       // :538-540
-                for (uint32_t li = 0; li < sc.nlights; ++li) {                                      // :557-559
-                    V3 c = lit(1 + li) ? contrib(1 + li) : mk(0, 0, 0);
-                    direct = add(direct, cmul(albedo, c));
+                auto term = [&](int k) -> V3 {          // contribution of shadow slot k if it was cast and not occluded
+                    if (!(need >> k & 1u)) return mk(0, 0, 0);
+                    const float4 v = shp[k];
+                    return f2u(v.w) == 0u ? mk(v.x, v.y, v.z) : mk(0, 0, 0);
+                };
+                if (sc.sky.kind != PTMI_SKY_NONE && (need & 1u)) {                                  // :538-540
+                    const float4 v = shp[0];
+                    if (f2u(v.w) == 0u) direct = add(direct, mk(v.x, v.y, v.z));
                 }
-                if (sc.nemissive > 0) {                                                             // :617
-                    V3 c = lit(1 + (int)sc.nlights) ? contrib(1 + (int)sc.nlights) : mk(0, 0, 0);
-                    direct = add(direct, c);
-                }
-                FRV_SET(depth, F_DIRECT, direct);
-                if (FRI(depth, F_BOUNCES) > 0) { state = ST_GI_LOOP; continue; }                    // :622
+                for (uint32_t li = 0; li < sc.nlights; ++li)                                        // :557-559
+                    direct = add(direct, cmul(albedo, term(1 + (int)li)));
+                if (sc.nemissive > 0) direct = add(direct, term(1 + (int)sc.nlights));              // :617
+                FV_SET(F_DIRECT, direct);
+                if (FI(F_BOUNCES) > 0) { state = ST_GI_LOOP; continue; }                            // :622
                 state = ST_DIFFUSE_FINAL; continue;
             }
             if (state == ST_GI_LOOP) {                                                              // :636-647
-                if (!have_hit) { load_hit(depth, h); have_hit = true; }
-                const int s = FRI(depth, F_S);
+                if (!have_hit) { load_hit(h); have_hit = true; }
+                const int s = FI(F_S);
                 if (s < ra.p.scatter_rays) {
                     V3 t1, t2; tangent_frame(h.normal, t1, t2);
                     V3 dir = cosine_sample2(rng, h.normal, t1, t2);
                     // bounces > 0 and the energy is this frame's own (already >= 1e-2): the child always runs
-                    FRU(depth, F_PHASE) = PH_GI_WAIT;
-                    push_child(depth, FRI(depth, F_BOUNCES) - 1, FRI(depth, F_BINDEX) + 1, h.normal, false,
-                               FRF(depth, F_ENERGY), add(h.P, scale(h.normal, (float)0.001)), dir);
+                    FU_SET(F_PHASE, PH_GI_WAIT);
+                    push_child(depth, FI(F_BOUNCES) - 1, FI(F_BINDEX) + 1, h.normal, false,
+                               FW(F_ENERGY), add(h.P, scale(h.normal, (float)0.001)), dir);
                     depth++; want_extend = true; break;
                 }
-                FRV_SET(depth, F_SUM, scale(FRV(depth, F_SUM), 1.0f / (float)ra.p.scatter_rays));
+                FV_SET(F_SUM, scale(FV(F_SUM), 1.0f / (float)ra.p.scatter_rays));
                 state = ST_DIFFUSE_FINAL; continue;
             }
             if (state == ST_DIFFUSE_FINAL) {                                                        // :658-667
-                if (!have_hit) { load_hit(depth, h); have_hit = true; }
+                if (!have_hit) { load_hit(h); have_hit = true; }
                 const PtMaterial &m = sc.mats[h.mat];
-                V3 indirect = FRI(depth, F_BOUNCES) > 0 ? FRV(depth, F_SUM) : mk(0, 0, 0);
-                V3 fin = FRV(depth, F_DIRECT);
+                V3 indirect = FI(F_BOUNCES) > 0 ? FV(F_SUM) : mk(0, 0, 0);
+                V3 fin = FV(F_DIRECT);
                 fin = add(fin, scale(mk(m.kd), ra.p.ambient));
                 fin = add(fin, scale(indirect, 1.0f));
-                if (FRI(depth, F_BINDEX) == 0 && is_emissive(m)) fin = add(fin, mk(m.ke));
+                if (FI(F_BINDEX) == 0 && is_emissive(m)) fin = add(fin, mk(m.ke));
                 diffuse_events++;
-                FRV_SET(depth, F_DIFF, fin);
-                FRV_SET(depth, F_SUM, mk(0, 0, 0));          // reflective component stays zero on this branch
+                FV_SET(F_DIFF, fin);
+                FV_SET(F_SUM, mk(0, 0, 0));          // reflective component stays zero on this branch
                 state = ST_COMBINE; continue;
             }
             if (state == ST_REFL_LOOP) {                                                            // :670-722
-                if (!have_hit) { load_hit(depth, h); have_hit = true; }
+                if (!have_hit) { load_hit(h); have_hit = true; }
                 const PtMaterial &m = sc.mats[h.mat];
-                const int bounces = FRI(depth, F_BOUNCES);
+                const int bounces = FI(F_BOUNCES);
                 bool pushed = false;
-                while (FRI(depth, F_S) < ra.p.scatter_rays) {
+                while (FI(F_S) < ra.p.scatter_rays) {
                     float roughness = 1.0f / (1.0f + m.ns / 100.0f);
                     float dp = dot(h.rd, h.normal);
                     V3 reflDir = normalize(sub(h.rd, scale(h.normal, 2.0f * dp)));
                     V3 sd = sample_glossy(rng, reflDir, roughness);
                     if (bounces - 1 < 0) {          // the child returns Vec3{} at its entry test (:16)
-                        FRV_SET(depth, F_SUM, add(FRV(depth, F_SUM), mk(0, 0, 0)));
-                        FRI(depth, F_S) = FRI(depth, F_S) + 1;
+                        FV_SET(F_SUM, add(FV(F_SUM), mk(0, 0, 0)));
+                        FI_SET(F_S, FI(F_S) + 1);
                         continue;
                     }
-                    FRU(depth, F_PHASE) = PH_REFL_WAIT;
-                    push_child(depth, bounces - 1, FRI(depth, F_BINDEX) + 1, h.normal, true, FRF(depth, F_ENERGY),
+                    FU_SET(F_PHASE, PH_REFL_WAIT);
+                    push_child(depth, bounces - 1, FI(F_BINDEX) + 1, h.normal, true, FW(F_ENERGY),
                                add(h.P, scale(h.normal, (float)0.001)), sd);
                     depth++; want_extend = true; pushed = true; break;
                 }
                 if (pushed) break;
-                V3 sum = scale(FRV(depth, F_SUM), 1.0f / (float)ra.p.scatter_rays);
+                V3 sum = scale(FV(F_SUM), 1.0f / (float)ra.p.scatter_rays);
                 sum = cmul(sum, mk(m.ks));
-                FRV_SET(depth, F_SUM, add(sum, FRV(depth, F_REFR)));                                // :165, :211
+                FV_SET(F_SUM, add(sum, FV(F_REFR)));                                                // :165, :211
                 state = ST_COMBINE; continue;
             }
             if (state == ST_COMBINE) {                                                              // :218-223
-                V3 refr = FRV(depth, F_REFR);
+                V3 refr = FV(F_REFR);
                 float diffuseScale = 1.0f;
                 if (length(refr) > 0.0f) diffuseScale = (float)0.1;
-                V3 fin = add(add(add(scale(FRV(depth, F_DIFF), diffuseScale), mk(0, 0, 0)), FRV(depth, F_SUM)), refr);
-                ret = scale(fin, FRF(depth, F_DG));
+                V3 fin = add(add(add(scale(FV(F_DIFF), diffuseScale), mk(0, 0, 0)), FV(F_SUM)), refr);
+                ret = scale(fin, FW(F_DG));
                 state = ST_RETURN; continue;
             }
             // ST_RETURN: hand `ret` to the caller frame
             if (depth == 0) {
-                float *o = pl.out + 3 * (size_t)pl.sid[slot];
+                float *o = pl.out + 3 * (size_t)sid;
                 o[0] = ret.x; o[1] = ret.y; o[2] = ret.z;
                 finished = true; break;
             }
             depth--; have_hit = false;
-            const uint32_t ph = FRU(depth, F_PHASE);
+            load_frame(depth);
+            const uint32_t ph = FU(F_PHASE);
             if (ph == PH_REFR_WAIT) {                                                               // :78, :89
-                FRV_SET(depth, F_REFR, scale(ret, FRF(depth, F_ENERGY)));
+                FV_SET(F_REFR, scale(ret, FW(F_ENERGY)));
                 state = ST_MATERIAL;
             } else if (ph == PH_GI_WAIT) {                                                          // :640-645
-                load_hit(depth, h); have_hit = true;
+                load_hit(h); have_hit = true;
                 V3 c = cmul(ret, mk(sc.mats[h.mat].kd));
-                FRV_SET(depth, F_SUM, add(FRV(depth, F_SUM), c));
-                FRI(depth, F_S) = FRI(depth, F_S) + 1;
+                FV_SET(F_SUM, add(FV(F_SUM), c));
+                FI_SET(F_S, FI(F_S) + 1);
                 state = ST_GI_LOOP;
             } else {                                                                                // PH_REFL_WAIT :715
-                FRV_SET(depth, F_SUM, add(FRV(depth, F_SUM), ret));
-                FRI(depth, F_S) = FRI(depth, F_S) + 1;
+                FV_SET(F_SUM, add(FV(F_SUM), ret));
+                FI_SET(F_S, FI(F_S) + 1);
                 state = ST_REFL_LOOP;
             }
         }
-        pl.depth[slot] = depth;
-        pl.rng_ctr[slot] = rng.ctr;
-        pl.trk_len[slot] = trk_len;
-#undef FRF
-#undef FRI
-#undef FRU
-#undef FRV
-#undef FRV_SET
-#undef TRK
+        if (err && !finished) {
+            atomicOr(&counters[CNT_ERROR], (unsigned long long)err);
+            want_extend = want_shadow = false; n_sray = 0; finished = true;
+        }
+        if (!finished) {
+            hd[0] = make_float4(h0.x, h0.y, u2f(rng.ctr), i2f(depth));
+            hd[1] = make_float4(u2f(trk_len), h1.y, h1.z, h1.w);
+            if (want_extend) {
+                hd[2] = make_float4(h2.x, h2.y, cur_o.x, cur_o.y);
+                hd[3] = make_float4(cur_o.z, cur_d.x, cur_d.y, cur_d.z);
+            }
+        }
+#undef FW
+#undef FV
+#undef FV_SET
+#undef FI
+#undef FU
+#undef FI_SET
+#undef FU_SET
     }
     // ---- queue compaction: one atomic per wave and queue ----
     uint32_t pe = wave_append(&pl.qcnt[Q_WORDS + Q_EXT], want_extend);
@@ -568,12 +629,11 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
         base = __shfl((long long)base, 63);
         if (n_sray) {
             uint32_t pos = (uint32_t)base + (incl - n_sray);
-            const uint32_t need = ((uint32_t *)pl.fr)[((size_t)pl.depth[slot] * NF + F_NEED) * cap + slot];
+            const float4 *park = pl.park + (size_t)slot * pl.nshadow * 2;
             for (int k = 0; k < pl.nshadow; ++k) {
-                if (!(need >> k & 1u)) continue;
-                const size_t park = (size_t)cap * pl.nshadow + (size_t)k * cap + slot;
-                float4 a = pl.q_sray_a[park], b = pl.q_sray_b[park];
-                b.w = __uint_as_float((uint32_t)((size_t)k * cap + slot));
+                if (!(need_out >> k & 1u)) continue;
+                float4 a = park[2 * k], b = park[2 * k + 1];
+                b.w = u2f(slot * (uint32_t)pl.nshadow + (uint32_t)k);
                 pl.q_sray_a[pos] = a; pl.q_sray_b[pos] = b;
                 ++pos;
             }
@@ -608,7 +668,8 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float *out, uint3
 struct RenderState {
     // scene (device)
     bool have_scene = false;
-    float *d_verts = nullptr; uint32_t *d_tri_idx = nullptr; float *d_normals = nullptr; uint32_t *d_tri_mat = nullptr;
+    float4 *d_stri = nullptr;            // per-triangle shading record (DevScene::stri)
+    uint32_t nmats = 0;
     PtMaterial *d_mats = nullptr; uint32_t *d_emissive = nullptr; uint32_t nemissive = 0;
     PtLight *d_lights = nullptr; uint32_t nlights = 0;
     PtSky sky{}; uint16_t *d_sky_img = nullptr;
@@ -625,7 +686,7 @@ namespace ptmi {
 void free_scene(ptmi_ctx *ctx) {
     RenderState *rs = ctx->render;
     if (!rs) return;
-    void *ptrs[] = {rs->d_verts, rs->d_tri_idx, rs->d_normals, rs->d_tri_mat, rs->d_mats, rs->d_emissive, rs->d_lights,
+    void *ptrs[] = {rs->d_stri, rs->d_mats, rs->d_emissive, rs->d_lights,
                     rs->d_sky_img, rs->pool_mem, rs->d_out, rs->d_accum, rs->d_counts};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete rs;
@@ -661,10 +722,24 @@ extern "C" int ptmi_upload_scene(ptmi_ctx *ctx, const PtMaterial *materials, uin
     RenderState *rs = ctx->render;
     rs->have_scene = false;
     int rc;
-    if ((rc = upload(ctx, rs->d_verts, ctx->verts.data(), ctx->verts.size()))) return rc;
-    if ((rc = upload(ctx, rs->d_tri_idx, ctx->tri_idx.data(), ctx->tri_idx.size()))) return rc;
-    if ((rc = upload(ctx, rs->d_normals, corner_normals, (size_t)ntris * 9))) return rc;
-    if ((rc = upload(ctx, rs->d_tri_mat, tri_material, (size_t)ntris))) return rc;
+    {   // shading records: what shade needs about a hit triangle in one 80-byte gather (vnmu.Vertices / Normals /
+        // Materials by tri.Index, tracer.go:38-48)
+        std::vector<float> rec((size_t)ntris * 20 + 4, 0.0f);
+        for (uint64_t t = 0; t < ntris; ++t) {
+            float *r = rec.data() + t * 20;
+            for (int c = 0; c < 3; ++c) {
+                const float *v = ctx->verts.data() + 3 * (size_t)ctx->tri_idx[3 * t + c];
+                r[3 * c] = v[0]; r[3 * c + 1] = v[1]; r[3 * c + 2] = v[2];
+            }
+            std::memcpy(r + 9, corner_normals + 9 * t, 9 * sizeof(float));
+            const uint32_t mid = tri_material[t];
+            std::memcpy(r + 18, &mid, 4);
+        }
+        float *d = nullptr;
+        if ((rc = upload(ctx, d, rec.data(), rec.size()))) return rc;
+        if (rs->d_stri) (void)hipFree(rs->d_stri);
+        rs->d_stri = (float4 *)d;
+    }
     if ((rc = upload(ctx, rs->d_mats, materials, (size_t)nmaterials))) return rc;
     if ((rc = upload(ctx, rs->d_lights, lights, (size_t)nlights))) return rc;
     std::vector<uint32_t> em;                                   // renderer.go:311-321
@@ -675,6 +750,7 @@ extern "C" int ptmi_upload_scene(ptmi_ctx *ctx, const PtMaterial *materials, uin
     if ((rc = upload(ctx, rs->d_emissive, em.data(), em.size()))) return rc;
     rs->nemissive = (uint32_t)em.size();
     rs->nlights = (uint32_t)nlights;
+    rs->nmats = (uint32_t)nmaterials;
     rs->sky = *sky;
     if (sky->kind == PTMI_SKY_IMAGE) {
         if ((rc = upload(ctx, rs->d_sky_img, sky_image, (size_t)sky->image_width * sky->image_height * 3))) return rc;
@@ -702,27 +778,19 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces) {
     // every TraceRay invocation can push one index and the sibling subtrees share the tracker, so its history is
     // bounded by the number of invocations, 2^(bounces+1)-1 (capped at 64 entries, like the oracle)
     p.ntrk = bounces + 1 >= 6 ? 64 : (1 << (bounces + 1)) + 1;
+    p.ntrk = (p.ntrk + 3) / 4 * 4;
     size_t off = 0;
     const size_t c = cap;
-    size_t o_sid = carve(off, 4 * c), o_key = carve(off, 4 * c), o_ctr = carve(off, 4 * c), o_depth = carve(off, 4 * c);
-    size_t o_tl = carve(off, 4 * c), o_trk = carve(off, 4 * c * p.ntrk);
-    size_t o_ro = carve(off, 12 * c), o_rd = carve(off, 12 * c);
-    size_t o_hs = carve(off, 4 * c), o_hp = carve(off, 4 * c), o_ht = carve(off, 4 * c), o_v0 = carve(off, 4 * c), o_v1 = carve(off, 4 * c);
-    size_t o_fr = carve(off, 4 * c * (size_t)p.nframes * NF);
-    size_t o_shc = carve(off, 12 * c * p.nshadow), o_sho = carve(off, c * p.nshadow);
+    size_t o_hdr = carve(off, 64 * c), o_fr = carve(off, 128 * c * (size_t)p.nframes), o_trk = carve(off, 4 * c * p.ntrk);
+    size_t o_sh = carve(off, 16 * c * p.nshadow), o_park = carve(off, 32 * c * p.nshadow);
     size_t o_qe0 = carve(off, 4 * c), o_qe1 = carve(off, 4 * c), o_qs0 = carve(off, 4 * c), o_qs1 = carve(off, 4 * c);
-    // shadow-ray queue: first cap*nshadow entries are the compacted queue, the next cap*nshadow the per-path parking area
-    size_t o_ra = carve(off, 16 * c * p.nshadow * 2), o_rb = carve(off, 16 * c * p.nshadow * 2);
+    size_t o_ra = carve(off, 16 * c * p.nshadow), o_rb = carve(off, 16 * c * p.nshadow);
     size_t o_free = carve(off, 4 * c), o_cnt = carve(off, 8 * 2 * Q_WORDS);
     PTMI_HIP(ctx, hipMalloc((void **)&rs->pool_mem, off));
     rs->pool_bytes = off;
     char *b = rs->pool_mem;
-    p.sid = (uint32_t *)(b + o_sid); p.rng_key = (uint32_t *)(b + o_key); p.rng_ctr = (uint32_t *)(b + o_ctr);
-    p.depth = (int32_t *)(b + o_depth); p.trk_len = (uint32_t *)(b + o_tl); p.trk = (float *)(b + o_trk);
-    p.ro = (float *)(b + o_ro); p.rd = (float *)(b + o_rd);
-    p.hstatus = (int32_t *)(b + o_hs); p.hprim = (int32_t *)(b + o_hp); p.ht = (float *)(b + o_ht);
-    p.vt0 = (float *)(b + o_v0); p.vt1 = (float *)(b + o_v1);
-    p.fr = (float *)(b + o_fr); p.sh_contrib = (float *)(b + o_shc); p.sh_occ = (uint8_t *)(b + o_sho);
+    p.hdr = (float4 *)(b + o_hdr); p.fr = (float4 *)(b + o_fr); p.trk = (float *)(b + o_trk);
+    p.sh = (float4 *)(b + o_sh); p.park = (float4 *)(b + o_park);
     p.q_ext[0] = (uint32_t *)(b + o_qe0); p.q_ext[1] = (uint32_t *)(b + o_qe1);
     p.q_shpath[0] = (uint32_t *)(b + o_qs0); p.q_shpath[1] = (uint32_t *)(b + o_qs1);
     p.q_sray_a = (float4 *)(b + o_ra); p.q_sray_b = (float4 *)(b + o_rb);
@@ -777,7 +845,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     pl.out = rs->d_out;
 
     DevScene sc{};
-    sc.verts = rs->d_verts; sc.tri_idx = rs->d_tri_idx; sc.normals = rs->d_normals; sc.tri_mat = rs->d_tri_mat;
+    sc.stri = rs->d_stri; sc.ntris = (uint32_t)(ctx->tri_idx.size() / 3); sc.nmats = rs->nmats;
     sc.mats = rs->d_mats; sc.emissive = rs->d_emissive; sc.nemissive = rs->nemissive;
     sc.lights = rs->d_lights; sc.nlights = rs->nlights; sc.sky = rs->sky; sc.sky_img = rs->d_sky_img;
     sc.bh = rs->bh; sc.has_bh = rs->has_bh;
@@ -840,6 +908,15 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             }
             n_ext = ne;
             cur ^= 1;
+        }
+        {   // integrator self-checks (ERR_*): any bit set means a path record was corrupt
+            unsigned long long e = 0;
+            PTMI_HIP(ctx, hipMemcpyAsync(&e, ctx->d_counters + CNT_ERROR, sizeof e, hipMemcpyDeviceToHost, s));
+            PTMI_HIP(ctx, hipStreamSynchronize(s));
+            if (e) {
+                (void)hipMemsetAsync(ctx->d_counters + CNT_ERROR, 0, sizeof e, s);
+                return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: integrator self-check failed, code " + std::to_string(e));
+            }
         }
         if (out_samples_host) {
             PTMI_HIP(ctx, hipMemcpyAsync(out_samples_host, rs->d_out, ra.total * 12, hipMemcpyDeviceToHost, s));
