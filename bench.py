@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L1_GATHER_PEAK_GBS = 13900.0   # measured: divergent 4 x dwordx4 gathers of L1-resident 64-B records (profiles/r01b/ubench_gather.txt)
 NODE_BYTES, TRI_BYTES, RAY_BYTES = 64, 48, 40
 
 
@@ -274,10 +275,15 @@ def main():
                        "sharding": f"replicated BVH, {world} independent ray batches"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "extend_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "kernel": "extend_vote_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "inner_visits_per_ray": round(c.inner_visits / n, 3),
-                         "tri_tests_per_ray": round(c.tri_tests / n, 3)},
+                         "tri_tests_per_ray": round(c.tri_tests / n, 3),
+                         "note": "the 67 MB tree is cache resident (traffic = fabric bytes from profiles/), so frac "
+                                 "can exceed 1; the ceiling this kernel runs against is the CU's L1 gather rate, "
+                                 "13.9 TB/s chip-wide measured by tools/ubench_gather.hip (profiles/r01b)",
+                         "l1_gather_peak_GBs": L1_GATHER_PEAK_GBS,
+                         "frac_of_l1_gather_peak": round(achieved / L1_GATHER_PEAK_GBS, 4)},
         }
         if render is not None:
             out["render"] = render

@@ -5,7 +5,7 @@ import csv, glob, os, sys, collections
 
 def main():
     root = sys.argv[1]
-    filt = sys.argv[2] if len(sys.argv) > 2 else "extend_kernel<24, false>"
+    filt = sys.argv[2] if len(sys.argv) > 2 else "extend_vote_kernel"
     for path in sorted(glob.glob(os.path.join(root, "pmc_*", "*", "*_counter_collection.csv"))):
         acc = collections.defaultdict(lambda: collections.defaultdict(float))   # counter -> dispatch -> sum
         for row in csv.DictReader(open(path)):
