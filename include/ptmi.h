@@ -143,7 +143,9 @@ typedef struct {
     float ni;           /* Refraction */
     float ns;           /* Shininess */
     uint32_t flags;
-    uint32_t pad[4];
+    uint32_t diffuse_map;   /* Material.DiffuseImage (obj.go:77): 1-based texture number of ptmi_upload_textures, 0 = nil */
+    uint32_t bump_map;      /* Material.BumpImage    (obj.go:78): same */
+    uint32_t pad[2];
 } PtMaterial;
 
 /* lights.go:11-15 (Sun: vec = Direction, used un-normalised as the reference does) and :32-35
@@ -201,6 +203,17 @@ typedef struct {
 int ptmi_upload_scene(ptmi_ctx *ctx, const PtMaterial *materials, uint64_t nmaterials, const uint32_t *tri_material,
                       const float *corner_normals, const PtLight *lights, uint64_t nlights, const PtSky *sky,
                       const uint16_t *sky_image, const PtBlackHole *blackhole);
+
+/* Replaces vnmu.UVs (vnmu.go:12) and the CachedImage table LoadObj builds (obj_loader.go:29-57,
+ * renderer.go:88-120) for SampleDiffuseMap / SampleBumpMap / TransformNormalToWorldSpace
+ * (renderer.go:122-169, :199-291; used by HandleDiffuseMaterial, tracer.go:468-514).  Call after
+ * ptmi_upload_scene.  uvs: 6 floats per triangle (u,v of corners A,B,C, already flipped v = 1-v as
+ * obj_loader.go:92 does); pixels: ntextures images back to back, row-major, each texel packed
+ * R | G<<8 | B<<16 | A<<24 exactly as CacheImage packs it (renderer.go:103-104).  A NaN or
+ * out-of-range texel coordinate is clamped into the image (the reference would index out of the
+ * pixel slice).  ntextures = 0 removes all textures. */
+int ptmi_upload_textures(ptmi_ctx *ctx, const float *uvs, uint32_t ntextures, const int32_t *widths,
+                         const int32_t *heights, const uint32_t *pixels);
 
 /* Replaces the body of the `calculate` worker (main.go:832-899) for one tile: for every pixel of the
  * rectangle (x0,y0,w,h) trace samples [spp_begin, spp_begin+spp_count) -- camera ray (main.go:862-874),

@@ -36,7 +36,11 @@ typedef struct {
     float kd[3], ks[3], ke[3];
     float ni, ns;
     uint32_t flags;          /* 1 = name has prefix "Glass" (tracer.go:49), 2 = name == "AccretionDisk" (:95) */
+    uint32_t diffuse_map, bump_map;   /* 1-based texture numbers, 0 = nil (Material.DiffuseImage / BumpImage, obj.go:77-78) */
 } orc_material;
+
+/* renderer.go:88-92 CachedImage: packed R | G<<8 | B<<16 | A<<24 (renderer.go:103-104) */
+typedef struct { const uint32_t *pixels; int width, height; } orc_image;
 
 typedef struct { int kind; v3 color; v3 vec; float intensity; } orc_light;   /* kind 0 Sun, 1 PointLight */
 
@@ -59,6 +63,8 @@ typedef struct {
     orc_light *lights; uint64_t nlights;
     orc_sky sky;
     orc_blackhole bh;
+    const float *uvs;                /* vnmu.UVs: 6 per triangle (vnmu.go:12) */
+    orc_image *images; uint64_t nimages;
 } orc_scene;
 
 typedef struct {
@@ -334,6 +340,123 @@ static inline int quick(trace_ctx *tc, v3 o, v3 d, float range) {
 }
 
 /* tracer.go:443-668.  Returns colour; *indirect_emissive as the second result. */
+/* ---- textures: obj_loader.go:11-17, renderer.go:122-169, :199-291 ---- */
+
+/* obj_loader.go:11-17 */
+static float tile(float val) {
+    float ip;
+    float vf = modff(val, &ip);
+    if (vf < 0) vf = 1 + vf;
+    return vf;
+}
+
+typedef struct { uint8_t R, G, B, A; } rgba8;
+
+/* renderer.go:122-135.  Go's int() of a NaN or out-of-range float is implementation-specific and would index out of
+ * the pixel slice; the restatement clamps the texel index into the image (deviation, memory safety only). */
+static rgba8 sample_diffuse_map(const orc_image *img, float x, float y) {
+    float fx = x * (float)(img->width - 1), fy = y * (float)(img->height - 1);
+    int px = (fx == fx) ? (int)fx : 0, py = (fy == fy) ? (int)fy : 0;
+    if (px < 0) px = 0;
+    if (px > img->width - 1) px = img->width - 1;
+    if (py < 0) py = 0;
+    if (py > img->height - 1) py = img->height - 1;
+    uint32_t packed = img->pixels[(size_t)py * (size_t)img->width + (size_t)px];
+    rgba8 c = { (uint8_t)packed, (uint8_t)(packed >> 8), (uint8_t)(packed >> 16), (uint8_t)(packed >> 24) };
+    return c;
+}
+
+/* renderer.go:137-169 */
+static v3 sample_bump_map(const orc_image *img, float x, float y, float strength) {
+    float w = (float)img->width, h = (float)img->height;
+    float offsetX = 1.0f / w, offsetY = 1.0f / h;
+    rgba8 center = sample_diffuse_map(img, x, y);
+    rgba8 right = sample_diffuse_map(img, fmodf(x + offsetX, 1.0f), y);
+    rgba8 up = sample_diffuse_map(img, x, fmodf(y + offsetY, 1.0f));
+    float centerHeight = (((float)0.299 * (float)center.R + (float)0.587 * (float)center.G) + (float)0.114 * (float)center.B) / 255.0f;
+    float rightHeight = (((float)0.299 * (float)right.R + (float)0.587 * (float)right.G) + (float)0.114 * (float)right.B) / 255.0f;
+    float upHeight = (((float)0.299 * (float)up.R + (float)0.587 * (float)up.G) + (float)0.114 * (float)up.B) / 255.0f;
+    float dx = (rightHeight - centerHeight) * strength;
+    float dy = (upHeight - centerHeight) * strength;
+    v3 n = { -dx, -dy, 1.0f };
+    return v3_normalize(n);
+}
+
+/* renderer.go:199-291 */
+static v3 transform_normal_to_world(v3 tn, v3 wn, v3 A, v3 B, v3 C, const float *uv /* 6 floats of this triangle */) {
+    if (tn.x == 0 && tn.y == 0 && tn.z == 1) return wn;
+    v3 edge1 = v3_sub(B, A), edge2 = v3_sub(C, A);
+    float d1x = uv[2] - uv[0], d1y = uv[3] - uv[1], d2x = uv[4] - uv[0], d2y = uv[5] - uv[1];
+    float det = d1x * d2y - d2x * d1y;
+    if (fabsf(det) < (float)1e-6) {
+        v3 up = { 0, 1, 0 };
+        if (!(fabsf(wn.y) < (float)0.9)) { up.x = 1; up.y = 0; }
+        v3 tangent = v3_normalize(v3_cross(wn, up));
+        v3 bitangent = v3_normalize(v3_cross(wn, tangent));
+        v3 r = { (tn.x * tangent.x + tn.y * bitangent.x) + tn.z * wn.x,
+                 (tn.x * tangent.y + tn.y * bitangent.y) + tn.z * wn.y,
+                 (tn.x * tangent.z + tn.y * bitangent.z) + tn.z * wn.z };
+        return v3_normalize(r);
+    }
+    float invDet = 1.0f / det;
+    v3 tangent = { invDet * (d2y * edge1.x - d1y * edge2.x), invDet * (d2y * edge1.y - d1y * edge2.y),
+                   invDet * (d2y * edge1.z - d1y * edge2.z) };
+    v3 bitangent = { invDet * (-d2x * edge1.x + d1x * edge2.x), invDet * (-d2x * edge1.y + d1x * edge2.y),
+                     invDet * (-d2x * edge1.z + d1x * edge2.z) };
+    tangent = v3_normalize(v3_sub(tangent, v3_scale(wn, v3_dot(tangent, wn))));
+    v3 calc = v3_cross(wn, tangent);
+    if (v3_dot(bitangent, calc) < 0) bitangent = v3_normalize(v3_scale(calc, -1.0f));
+    else bitangent = v3_normalize(calc);
+    v3 r = { (tn.x * tangent.x + tn.y * bitangent.x) + tn.z * wn.x,
+             (tn.x * tangent.y + tn.y * bitangent.y) + tn.z * wn.y,
+             (tn.x * tangent.z + tn.y * bitangent.z) + tn.z * wn.z };
+    return v3_normalize(r);
+}
+
+/* tracer.go:468-514: albedo and shading normal of HandleDiffuseMaterial for a textured material */
+static void diffuse_surface(const orc_scene *sc, const orc_material *m, int64_t tri, v3 P, v3 *albedo, v3 *normal) {
+    *albedo = v3f(m->kd);
+    const int has_image = (m->diffuse_map || m->bump_map) && sc->uvs && sc->images;     /* Material.HasImage (obj_loader.go:54) */
+    if (!has_image) return;
+    const float *uv = sc->uvs + 6 * (size_t)tri;
+    v3 A = vert(sc, sc->tri_idx[3 * (size_t)tri]), B = vert(sc, sc->tri_idx[3 * (size_t)tri + 1]), C = vert(sc, sc->tri_idx[3 * (size_t)tri + 2]);
+    v3 v0 = v3_sub(B, A), v1 = v3_sub(C, A), v2 = v3_sub(P, A);
+    float dot00 = v3_dot(v0, v0), dot01 = v3_dot(v0, v1), dot02 = v3_dot(v0, v2), dot11 = v3_dot(v1, v1), dot12 = v3_dot(v1, v2);
+    float invDenom = 1.0f / (dot00 * dot11 - dot01 * dot01);
+    float u = (dot11 * dot02 - dot01 * dot12) * invDenom;
+    float v = (dot00 * dot12 - dot01 * dot02) * invDenom;
+    float w = 1.0f - u - v;
+    float x = tile((w * uv[0] + u * uv[2]) + v * uv[4]);
+    float y = tile((w * uv[1] + u * uv[3]) + v * uv[5]);
+    if (m->diffuse_map && m->diffuse_map <= sc->nimages) {
+        rgba8 c = sample_diffuse_map(&sc->images[m->diffuse_map - 1], x, y);
+        albedo->x = powf((float)c.R / 255.0f, (float)2.2);
+        albedo->y = powf((float)c.G / 255.0f, (float)2.2);
+        albedo->z = powf((float)c.B / 255.0f, (float)2.2);
+    }
+    if (m->bump_map && m->bump_map <= sc->nimages) {
+        v3 bn = sample_bump_map(&sc->images[m->bump_map - 1], x, y, 1.0f);
+        *normal = v3_normalize(transform_normal_to_world(bn, *normal, A, B, C, uv));
+    }
+}
+
+/* probes for the known-answer tests (tests/test_oracle.py) */
+float orc_probe_tile(float v) { return tile(v); }
+uint32_t orc_probe_texel(const uint32_t *pixels, int w, int h, float x, float y) {
+    orc_image img = { pixels, w, h };
+    rgba8 c = sample_diffuse_map(&img, x, y);
+    return (uint32_t)c.R | ((uint32_t)c.G << 8) | ((uint32_t)c.B << 16) | ((uint32_t)c.A << 24);
+}
+void orc_probe_bump(const uint32_t *pixels, int w, int h, float x, float y, float strength, float *out3) {
+    orc_image img = { pixels, w, h };
+    v3 n = sample_bump_map(&img, x, y, strength);
+    out3[0] = n.x; out3[1] = n.y; out3[2] = n.z;
+}
+void orc_probe_tbn(const float *tn, const float *wn, const float *abc9, const float *uv6, float *out3) {
+    v3 r = transform_normal_to_world(v3f(tn), v3f(wn), v3f(abc9), v3f(abc9 + 3), v3f(abc9 + 6), uv6);
+    out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
+
 static v3 handle_diffuse(trace_ctx *tc, v3 ro, v3 rd, int bounces, int64_t tri, v3 P, v3 normal, int bounceIndex,
                          float energy, int *indirect_emissive) {
     const orc_scene *sc = tc->sc;
@@ -342,7 +465,8 @@ static v3 handle_diffuse(trace_ctx *tc, v3 ro, v3 rd, int bounces, int64_t tri, 
     v3 zero = { 0, 0, 0 };
     *indirect_emissive = 0;
     if (bounceIndex > 0 && is_emissive(m)) { *indirect_emissive = 1; return v3f(m->ke); }      /* :461-465 */
-    v3 albedo = v3f(m->kd);                                                                  /* :468,:517 */
+    v3 albedo;                                                                               /* :468-521 */
+    diffuse_surface(sc, m, tri, P, &albedo, &normal);
     v3 ambientContribution = v3_scale(albedo, tc->p.ambient);                                /* :524 */
     v3 direct = zero;
     v3 rayOrigin = v3_add(P, v3_scale(normal, (float)0.001));                                /* :528 */
@@ -564,6 +688,7 @@ orc_scene *orc_scene_create(const orc_bvh *bvh, const float *verts, const uint32
         orc_material *m = &s->materials[i];
         memcpy(m->kd, r, 12); memcpy(m->ks, r + 3, 12); memcpy(m->ke, r + 6, 12);
         m->ni = r[9]; m->ns = r[10]; memcpy(&m->flags, r + 11, 4);
+        memcpy(&m->diffuse_map, r + 12, 4); memcpy(&m->bump_map, r + 13, 4);
     }
     s->emissive = (uint32_t *)malloc(sizeof(uint32_t) * (ntris ? ntris : 1));
     for (uint64_t t = 0; t < ntris; ++t)            /* renderer.go:311-321 */
@@ -583,7 +708,19 @@ orc_scene *orc_scene_create(const orc_bvh *bvh, const float *verts, const uint32
     }
     return s;
 }
-void orc_scene_free(orc_scene *s) { if (!s) return; free(s->materials); free(s->emissive); free(s->lights); free(s); }
+/* vnmu.UVs + the CachedImage table (obj_loader.go:29-57); pixels = all images back to back, borrowed */
+void orc_scene_set_textures(orc_scene *s, const float *uvs, uint64_t nimages, const int32_t *widths, const int32_t *heights,
+                            const uint32_t *pixels) {
+    free(s->images);
+    s->uvs = uvs; s->nimages = nimages;
+    s->images = (orc_image *)calloc(nimages ? nimages : 1, sizeof(orc_image));
+    size_t off = 0;
+    for (uint64_t i = 0; i < nimages; ++i) {
+        s->images[i].pixels = pixels + off; s->images[i].width = widths[i]; s->images[i].height = heights[i];
+        off += (size_t)widths[i] * (size_t)heights[i];
+    }
+}
+void orc_scene_free(orc_scene *s) { if (!s) return; free(s->materials); free(s->emissive); free(s->lights); free(s->images); free(s); }
 
 /* One primary sample: main.go:861-879.  cam = pos, fwd, right, up (xyz each), frustum distance. */
 static v3 sample_pixel(const orc_scene *sc, const orc_params *p, const float *cam, int X, int Y, uint32_t sample,

@@ -78,6 +78,7 @@ SIGNATURES = {
     "ptmi_reset_counters": (C.c_int, [_P]),
     "ptmi_counters": (C.c_int, [_P, C.POINTER(PtCounters)]),
     "ptmi_upload_scene": (C.c_int, [_P, _P, _U64, _U32, _F, _P, _U64, _P, C.POINTER(C.c_uint16), _P]),
+    "ptmi_upload_textures": (C.c_int, [_P, _F, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _U32]),
     "ptmi_render": (C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), C.c_int32, C.c_int32, C.c_int32,
                               C.c_int32, C.c_uint32, C.c_uint32, _F, _U32]),
     "ptmi_render_dev": (C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), C.c_int32, C.c_int32, C.c_int32,

@@ -54,6 +54,7 @@ enum { ERR_SLOT = 1, ERR_DEPTH = 2, ERR_PRIM = 4, ERR_MAT = 8, ERR_PHASE = 16 };
 struct DevScene {
     const float4 *stri;                  // shading record per triangle, 5 x float4: A B C, N0 N1 N2, material id
     uint32_t ntris, nmats;
+    const float *uvs; const TexDesc *tex; const uint32_t *tex_pixels; uint32_t ntex;   // vnmu.UVs + CachedImage table
     const PtMaterial *mats; const uint32_t *emissive; uint32_t nemissive;
     const PtLight *lights; uint32_t nlights;
     PtSky sky; const uint16_t *sky_img;
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool p
 
 struct Hit {            // a frame's hit, re-derived from the frame's stored ray + (t, prim)
     V3 ro, rd, P, normal, A, B, C;
+    V3 dnormal, albedo;  // what HandleDiffuseMaterial shades with (bump-mapped normal, textured albedo: tracer.go:468-514)
     int prim;
     uint32_t mat;
 };
@@ -299,6 +301,9 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
             if (FU(F_FLAGS) & FL_FLIPPED) n = scale(n, -1.0f);                      // :53
             h.normal = n;
             h.mat = tr.mat;
+            h.dnormal = n;
+            diffuse_surface(sc.mats[h.mat], sc.uvs, sc.tex, sc.ntex, sc.tex_pixels, (uint32_t)h.prim, h.P, h.A, h.B, h.C,
+                            h.albedo, h.dnormal);
         };
         // park the top frame, push a child TraceRay invocation above it and request its extend
         auto push_child = [&](int dep, int bounces, int bindex, V3 lastN, bool specular, float energy, V3 o, V3 d) {
@@ -382,6 +387,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                     }
                     // the child returns Vec3{} at its entry test: refraction = {} * energy
                     FV_SET(F_REFR, scale(mk(0, 0, 0), energy));
+                    have_hit = false;       // the normal may have been flipped: re-derive the diffuse normal from the flag
                 }
                 state = ST_MATERIAL; continue;
             }
@@ -412,8 +418,8 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                 }
                 // direct lighting of HandleDiffuseMaterial (:523-618): draw in the reference's order, stage the
                 // shadow rays, resume in ST_SHADOW_DONE once `connect` has answered them
-                const V3 albedo = mk(m.kd);
-                const V3 rayOrigin = add(h.P, scale(h.normal, (float)0.001));                       // :528
+                const V3 albedo = h.albedo;
+                const V3 rayOrigin = add(h.P, scale(h.dnormal, (float)0.001));                       // :528
                 uint32_t need = 0;
                 auto stage = [&](int k, V3 o, V3 d, float range, V3 contrib) {
                     need |= 1u << k;
@@ -424,22 +430,22 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                     n_sray++;
                 };
                 if (sc.sky.kind != PTMI_SKY_NONE) {                                                 // :531-542
-                    V3 t1, t2; tangent_frame(h.normal, t1, t2);
-                    V3 rn = cosine_sample2(rng, h.normal, t1, t2);
+                    V3 t1, t2; tangent_frame(h.dnormal, t1, t2);
+                    V3 rn = cosine_sample2(rng, h.dnormal, t1, t2);
                     stage(0, rayOrigin, rn, 100000.0f, cmul(sky_sample(sc.sky, sc.sky_img, rn), albedo));
                 }
                 for (uint32_t li = 0; li < sc.nlights; ++li) {                                      // :545-560
                     const PtLight &L = sc.lights[li];
                     if (L.kind == PTMI_LIGHT_SUN) {                                                 // lights.go:18-28
                         V3 ld = mk(L.vec);
-                        float ndotr = dot(ld, h.normal);
+                        float ndotr = dot(ld, h.dnormal);
                         if (!(ndotr < 0.0f)) stage(1 + li, rayOrigin, ld, ra.p.step_size, scale(mk(L.color), ndotr * L.intensity));
                     } else {                                                                        // lights.go:38-54
                         V3 ld = normalize(sub(mk(L.vec), rayOrigin));
                         V3 toLight = sub(mk(L.vec), rayOrigin);
                         float distance = length(toLight);
                         toLight = normalize(toLight);
-                        float ndotl = dot(h.normal, toLight);
+                        float ndotl = dot(h.dnormal, toLight);
                         if (!(ndotl <= 0.0f)) {
                             float att = 1.0f / (distance * distance);
                             stage(1 + li, rayOrigin, ld, distance, scale(mk(L.color), ndotl * L.intensity * att));
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                     }
                 }
                 if (sc.nemissive > 0) {                                                             // :562-618
-                    V3 eo = add(h.P, scale(h.normal, (float)0.01));
+                    V3 eo = add(h.P, scale(h.dnormal, (float)0.01));
                     uint32_t choice = rng_intn(rng, sc.nemissive);
                     uint32_t et = sc.emissive[choice];
                     if (et >= sc.ntris) { err |= ERR_PRIM; et = 0; }
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                     V3 toLight = sub(lightPoint, eo);
                     float distance = length(toLight);
                     toLight = normalize(toLight);
-                    float ndotl = dot(toLight, h.normal);
+                    float ndotl = dot(toLight, h.dnormal);
                     if (!(ndotl <= 0.0f)) {
                         V3 ec = mk(0, 0, 0);
                         float sndorl = -dot(toLight, lsn);
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                             float geometryTerm = ndotl * sndorl / (distance * distance);
                             float pdf = triangle_area(e.A, e.B, e.C);
                             pdf = 1.0f / (pdf * (float)sc.nemissive);
-                            float pdf_brdf = dot(h.normal, toLight) / PT_PI32;
+                            float pdf_brdf = dot(h.dnormal, toLight) / PT_PI32;
                             float pdf_sa = pdf * (distance * distance) / sndorl;
                             float weight = mis_weight(pdf_sa, pdf_brdf);
                             V3 le = mk(sc.mats[e.mat].ke);
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
             if (state == ST_SHADOW_DONE) {
                 if (!have_hit) { load_hit(h); have_hit = true; }
                 const PtMaterial &m = sc.mats[h.mat];
-                const V3 albedo = mk(m.kd);
+                const V3 albedo = h.albedo;
                 const uint32_t need = FU(F_NEED);
                 V3 direct = mk(0, 0, 0);
                 auto term = [&](int k) -> V3 {          // contribution of shadow slot k if it was cast and not occluded
@@ -506,12 +512,12 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                 if (!have_hit) { load_hit(h); have_hit = true; }
                 const int s = FI(F_S);
                 if (s < ra.p.scatter_rays) {
-                    V3 t1, t2; tangent_frame(h.normal, t1, t2);
-                    V3 dir = cosine_sample2(rng, h.normal, t1, t2);
+                    V3 t1, t2; tangent_frame(h.dnormal, t1, t2);
+                    V3 dir = cosine_sample2(rng, h.dnormal, t1, t2);
                     // bounces > 0 and the energy is this frame's own (already >= 1e-2): the child always runs
                     FU_SET(F_PHASE, PH_GI_WAIT);
-                    push_child(depth, FI(F_BOUNCES) - 1, FI(F_BINDEX) + 1, h.normal, false,
-                               FW(F_ENERGY), add(h.P, scale(h.normal, (float)0.001)), dir);
+                    push_child(depth, FI(F_BOUNCES) - 1, FI(F_BINDEX) + 1, h.dnormal, false,
+                               FW(F_ENERGY), add(h.P, scale(h.dnormal, (float)0.001)), dir);
                     depth++; want_extend = true; break;
                 }
                 FV_SET(F_SUM, scale(FV(F_SUM), 1.0f / (float)ra.p.scatter_rays));
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                 const PtMaterial &m = sc.mats[h.mat];
                 V3 indirect = FI(F_BOUNCES) > 0 ? FV(F_SUM) : mk(0, 0, 0);
                 V3 fin = FV(F_DIRECT);
-                fin = add(fin, scale(mk(m.kd), ra.p.ambient));
+                fin = add(fin, scale(h.albedo, ra.p.ambient));
                 fin = add(fin, scale(indirect, 1.0f));
                 if (FI(F_BINDEX) == 0 && is_emissive(m)) fin = add(fin, mk(m.ke));
                 diffuse_events++;
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                 state = ST_MATERIAL;
             } else if (ph == PH_GI_WAIT) {                                                          // :640-645
                 load_hit(h); have_hit = true;
-                V3 c = cmul(ret, mk(sc.mats[h.mat].kd));
+                V3 c = cmul(ret, h.albedo);
                 FV_SET(F_SUM, add(FV(F_SUM), c));
                 FI_SET(F_S, FI(F_S) + 1);
                 state = ST_GI_LOOP;
@@ -670,6 +676,7 @@ struct RenderState {
     bool have_scene = false;
     float4 *d_stri = nullptr;            // per-triangle shading record (DevScene::stri)
     uint32_t nmats = 0;
+    float *d_uvs = nullptr; TexDesc *d_tex = nullptr; uint32_t *d_tex_pixels = nullptr; uint32_t ntex = 0;
     PtMaterial *d_mats = nullptr; uint32_t *d_emissive = nullptr; uint32_t nemissive = 0;
     PtLight *d_lights = nullptr; uint32_t nlights = 0;
     PtSky sky{}; uint16_t *d_sky_img = nullptr;
@@ -686,7 +693,7 @@ namespace ptmi {
 void free_scene(ptmi_ctx *ctx) {
     RenderState *rs = ctx->render;
     if (!rs) return;
-    void *ptrs[] = {rs->d_stri, rs->d_mats, rs->d_emissive, rs->d_lights,
+    void *ptrs[] = {rs->d_uvs, rs->d_tex, rs->d_tex_pixels, rs->d_stri, rs->d_mats, rs->d_emissive, rs->d_lights,
                     rs->d_sky_img, rs->pool_mem, rs->d_out, rs->d_accum, rs->d_counts};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete rs;
@@ -758,6 +765,36 @@ extern "C" int ptmi_upload_scene(ptmi_ctx *ctx, const PtMaterial *materials, uin
     rs->has_bh = blackhole ? 1 : 0;
     if (blackhole) rs->bh = *blackhole; else std::memset(&rs->bh, 0, sizeof rs->bh);
     rs->have_scene = true;
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_upload_textures(ptmi_ctx *ctx, const float *uvs, uint32_t ntextures, const int32_t *widths,
+                                    const int32_t *heights, const uint32_t *pixels) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_upload_textures: ctx is null");
+    RenderState *rs = ctx->render;
+    if (!rs || !rs->have_scene) return set_err(ctx, PTMI_ERR_NO_SCENE, "ptmi_upload_textures: upload a scene first");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    PTMI_HIP(ctx, hipDeviceSynchronize());
+    if (ntextures == 0) {
+        for (void *p : {(void *)rs->d_uvs, (void *)rs->d_tex, (void *)rs->d_tex_pixels}) if (p) (void)hipFree(p);
+        rs->d_uvs = nullptr; rs->d_tex = nullptr; rs->d_tex_pixels = nullptr; rs->ntex = 0;
+        return PTMI_OK;
+    }
+    if (!uvs || !widths || !heights || !pixels) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_textures: null array");
+    std::vector<TexDesc> desc(ntextures);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < ntextures; ++i) {
+        if (widths[i] < 1 || heights[i] < 1) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_textures: empty image");
+        if (total > 0xFFFFFFFFull) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_textures: more than 2^32 texels");
+        desc[i].offset = (uint32_t)total; desc[i].width = widths[i]; desc[i].height = heights[i]; desc[i].pad = 0;
+        total += (uint64_t)widths[i] * (uint64_t)heights[i];
+    }
+    int rc;
+    const size_t ntris = ctx->tri_idx.size() / 3;
+    if ((rc = upload(ctx, rs->d_uvs, uvs, ntris * 6))) return rc;
+    if ((rc = upload(ctx, rs->d_tex, desc.data(), desc.size()))) return rc;
+    if ((rc = upload(ctx, rs->d_tex_pixels, pixels, (size_t)total))) return rc;
+    rs->ntex = ntextures;
     return PTMI_OK;
 }
 
@@ -845,6 +882,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     pl.out = rs->d_out;
 
     DevScene sc{};
+    sc.uvs = rs->d_uvs; sc.tex = rs->d_tex; sc.tex_pixels = rs->d_tex_pixels; sc.ntex = rs->ntex;
     sc.stri = rs->d_stri; sc.ntris = (uint32_t)(ctx->tri_idx.size() / 3); sc.nmats = rs->nmats;
     sc.mats = rs->d_mats; sc.emissive = rs->d_emissive; sc.nemissive = rs->nemissive;
     sc.lights = rs->d_lights; sc.nlights = rs->nlights; sc.sky = rs->sky; sc.sky_img = rs->d_sky_img;

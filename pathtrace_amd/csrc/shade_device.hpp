@@ -266,4 +266,101 @@ __device__ __forceinline__ V3 disk_color(const PtBlackHole &bh, V3 world) {
     return scale(temp, nv);
 }
 
+// ---- textures: obj_loader.go:11-17, renderer.go:122-169, :199-291 -----------------------------------
+
+struct TexDesc { uint32_t offset; int32_t width, height; uint32_t pad; };   // one per texture, offset in texels
+
+// obj_loader.go:11-17
+__device__ __forceinline__ float tile_uv(float val) {
+    float ip;
+    float vf = modff(val, &ip);
+    if (vf < 0) vf = 1 + vf;
+    return vf;
+}
+
+// renderer.go:122-135; returns the packed texel.  NaN / out-of-range coordinates are clamped into the image.
+__device__ __forceinline__ uint32_t sample_diffuse_map(const uint32_t *pixels, const TexDesc &t, float x, float y) {
+    const float fx = x * (float)(t.width - 1), fy = y * (float)(t.height - 1);
+    int px = (fx == fx) ? (int)fx : 0, py = (fy == fy) ? (int)fy : 0;
+    px = px < 0 ? 0 : (px > t.width - 1 ? t.width - 1 : px);
+    py = py < 0 ? 0 : (py > t.height - 1 ? t.height - 1 : py);
+    return pixels[(size_t)t.offset + (size_t)py * (size_t)t.width + (size_t)px];
+}
+
+__device__ __forceinline__ float texel_height(uint32_t p) {     // renderer.go:152-154
+    const float R = (float)(p & 255u), G = (float)((p >> 8) & 255u), B = (float)((p >> 16) & 255u);
+    return (((float)0.299 * R + (float)0.587 * G) + (float)0.114 * B) / 255.0f;
+}
+
+// renderer.go:137-169
+__device__ __forceinline__ V3 sample_bump_map(const uint32_t *pixels, const TexDesc &t, float x, float y, float strength) {
+    const float w = (float)t.width, h = (float)t.height;
+    const float offsetX = 1.0f / w, offsetY = 1.0f / h;
+    const float centerHeight = texel_height(sample_diffuse_map(pixels, t, x, y));
+    const float rightHeight = texel_height(sample_diffuse_map(pixels, t, fmodf(x + offsetX, 1.0f), y));
+    const float upHeight = texel_height(sample_diffuse_map(pixels, t, x, fmodf(y + offsetY, 1.0f)));
+    const float dx = (rightHeight - centerHeight) * strength;
+    const float dy = (upHeight - centerHeight) * strength;
+    return normalize(mk(-dx, -dy, 1.0f));
+}
+
+// renderer.go:199-291; uv = the six UV floats of the triangle
+__device__ __forceinline__ V3 transform_normal_to_world(V3 tn, V3 wn, V3 A, V3 B, V3 C, const float *uv) {
+    if (tn.x == 0 && tn.y == 0 && tn.z == 1) return wn;
+    const V3 edge1 = sub(B, A), edge2 = sub(C, A);
+    const float d1x = uv[2] - uv[0], d1y = uv[3] - uv[1], d2x = uv[4] - uv[0], d2y = uv[5] - uv[1];
+    const float det = d1x * d2y - d2x * d1y;
+    V3 tangent, bitangent;
+    if (fabsf(det) < (float)1e-6) {
+        V3 up = mk(0, 1, 0);
+        if (!(fabsf(wn.y) < (float)0.9)) up = mk(1, 0, 0);
+        tangent = normalize(cross(wn, up));
+        bitangent = normalize(cross(wn, tangent));
+    } else {
+        const float invDet = 1.0f / det;
+        tangent = mk(invDet * (d2y * edge1.x - d1y * edge2.x), invDet * (d2y * edge1.y - d1y * edge2.y),
+                     invDet * (d2y * edge1.z - d1y * edge2.z));
+        bitangent = mk(invDet * (-d2x * edge1.x + d1x * edge2.x), invDet * (-d2x * edge1.y + d1x * edge2.y),
+                       invDet * (-d2x * edge1.z + d1x * edge2.z));
+        tangent = normalize(sub(tangent, scale(wn, dot(tangent, wn))));
+        const V3 calc = cross(wn, tangent);
+        if (dot(bitangent, calc) < 0) bitangent = normalize(scale(calc, -1.0f));
+        else bitangent = normalize(calc);
+    }
+    return normalize(mk((tn.x * tangent.x + tn.y * bitangent.x) + tn.z * wn.x,
+                        (tn.x * tangent.y + tn.y * bitangent.y) + tn.z * wn.y,
+                        (tn.x * tangent.z + tn.y * bitangent.z) + tn.z * wn.z));
+}
+
+// tracer.go:468-514: albedo and shading normal of HandleDiffuseMaterial for a textured material
+__device__ __forceinline__ void diffuse_surface(const PtMaterial &m, const float *uvs, const TexDesc *tex, uint32_t ntex,
+                                                const uint32_t *pixels, uint32_t prim, V3 P, V3 A, V3 B, V3 C,
+                                                V3 &albedo, V3 &normal) {
+    albedo = mk(m.kd);
+    if (!(m.diffuse_map || m.bump_map) || !uvs || !ntex) return;        // Material.HasImage (obj_loader.go:54)
+    float uv[6];
+    {
+        const float2 *p = (const float2 *)(uvs + 6 * (size_t)prim);
+        const float2 a = p[0], b = p[1], c = p[2];
+        uv[0] = a.x; uv[1] = a.y; uv[2] = b.x; uv[3] = b.y; uv[4] = c.x; uv[5] = c.y;
+    }
+    const V3 v0 = sub(B, A), v1 = sub(C, A), v2 = sub(P, A);
+    const float dot00 = dot(v0, v0), dot01 = dot(v0, v1), dot02 = dot(v0, v2), dot11 = dot(v1, v1), dot12 = dot(v1, v2);
+    const float invDenom = 1.0f / (dot00 * dot11 - dot01 * dot01);
+    const float u = (dot11 * dot02 - dot01 * dot12) * invDenom;
+    const float v = (dot00 * dot12 - dot01 * dot02) * invDenom;
+    const float w = 1.0f - u - v;
+    const float x = tile_uv((w * uv[0] + u * uv[2]) + v * uv[4]);
+    const float y = tile_uv((w * uv[1] + u * uv[3]) + v * uv[5]);
+    if (m.diffuse_map && m.diffuse_map <= ntex) {
+        const uint32_t c = sample_diffuse_map(pixels, tex[m.diffuse_map - 1], x, y);
+        albedo = mk(powf((float)(c & 255u) / 255.0f, (float)2.2), powf((float)((c >> 8) & 255u) / 255.0f, (float)2.2),
+                    powf((float)((c >> 16) & 255u) / 255.0f, (float)2.2));
+    }
+    if (m.bump_map && m.bump_map <= ntex) {
+        const V3 bn = sample_bump_map(pixels, tex[m.bump_map - 1], x, y, 1.0f);
+        normal = normalize(transform_normal_to_world(bn, normal, A, B, C, uv));
+    }
+}
+
 }  // namespace ptmi

@@ -72,6 +72,20 @@ class Renderer:
             lights.ctypes.data_as(C.c_void_p) if lights.size else None, lights.shape[0],
             sky.ctypes.data_as(C.c_void_p), _ptr(img, C.c_uint16) if img is not None else None,
             bh.ctypes.data_as(C.c_void_p) if bh is not None else None), self.ctx.handle)
+        self.upload_textures(getattr(sc, "uvs", None), getattr(sc, "textures", None))
+
+    def upload_textures(self, uvs, textures):
+        """vnmu.UVs + the CachedImage table (obj_loader.go:29-57): textures = list of [h,w] packed-RGBA u32 images."""
+        if not textures or uvs is None:
+            check(self._lib.ptmi_upload_textures(self.ctx.handle, None, 0, None, None, None), self.ctx.handle)
+            return
+        uv = np.ascontiguousarray(uvs, np.float32).reshape(-1, 6)
+        assert uv.shape[0] == self.bvh.ntris if hasattr(self.bvh, "ntris") else True
+        w = np.array([t.shape[1] for t in textures], np.int32)
+        h = np.array([t.shape[0] for t in textures], np.int32)
+        px = np.ascontiguousarray(np.concatenate([np.asarray(t, np.uint32).reshape(-1) for t in textures]))
+        check(self._lib.ptmi_upload_textures(self.ctx.handle, _ptr(uv, C.c_float), len(textures), _ptr(w, C.c_int32),
+                                             _ptr(h, C.c_int32), _ptr(px, C.c_uint32)), self.ctx.handle)
 
     @staticmethod
     def new_framebuffer(width, height) -> Framebuffer:

@@ -364,10 +364,13 @@ class SceneData:
     sky_image: np.ndarray | None = None   # [h,w,3] u16 equirect image for sky kind 3
     camera: Camera | None = None
     names: list = field(default_factory=list)
+    uvs: np.ndarray | None = None         # [nt,6] f32: u,v of corners A,B,C (vnmu.UVs, vnmu.go:12)
+    textures: list | None = None          # [h,w] u32 images packed R|G<<8|B<<16|A<<24 (CacheImage, renderer.go:94-119)
 
 
 # Rows are binary images of the C structs of include/ptmi.h (integer fields stored as their bits):
-# PtMaterial: Kd rgb, Ks rgb, Ke rgb, Ni, Ns, u32 flags, pad x4                      (obj.go:63-79)
+# PtMaterial: Kd rgb, Ks rgb, Ke rgb, Ni, Ns, u32 flags, u32 diffuse_map, u32 bump_map (1-based, 0 = nil), pad x2
+#                                                                                      (obj.go:63-79)
 MATERIAL_COLUMNS = 16
 # PtLight: i32 kind (0 sun, 1 point), color rgb, dir/pos xyz, intensity, pad x4      (lights.go:11-15,32-35)
 LIGHT_COLUMNS = 12
@@ -376,8 +379,10 @@ LIGHT_COLUMNS = 12
 SKY_COLUMNS = 16
 
 
-def material(kd=(0.7, 0.7, 0.7), ks=(0, 0, 0), ke=(0, 0, 0), ni=1.0, ns=0.0, flags=0):
+def material(kd=(0.7, 0.7, 0.7), ks=(0, 0, 0), ke=(0, 0, 0), ni=1.0, ns=0.0, flags=0, diffuse_map=0, bump_map=0):
     row = np.zeros(MATERIAL_COLUMNS, dtype=F32)
+    row[12:13].view(np.uint32)[0] = diffuse_map
+    row[13:14].view(np.uint32)[0] = bump_map
     row[0:3] = kd
     row[3:6] = ks
     row[6:9] = ke
@@ -484,6 +489,70 @@ def bunny_scene(blob_level=None, glass=False, emissive=False, seed=1, small=Fals
     return SceneData(verts=v, tris=f, normals=np.concatenate(normals, 0).astype(F32),
                      tri_material=np.concatenate(tri_mat).astype(U32), materials=np.stack(mats).astype(F32),
                      lights=np.stack([_sponza_sun()]).astype(F32), sky=_sponza_sky(), camera=cam)
+
+
+def pack_rgba(rgb):
+    """[h,w,3] (or [h,w,4]) uint8 -> packed texels as CacheImage stores them (renderer.go:103-104)."""
+    rgb = np.asarray(rgb, dtype=np.uint32)
+    a = rgb[..., 3] if rgb.shape[-1] == 4 else np.full(rgb.shape[:2], 255, dtype=np.uint32)
+    return (rgb[..., 0] | (rgb[..., 1] << 8) | (rgb[..., 2] << 16) | (a << 24)).astype(np.uint32)
+
+
+def procedural_texture(width, height, seed, kind="checker"):
+    """Deterministic test image: a coloured checker or smooth value noise (for bump maps)."""
+    yy, xx = np.mgrid[0:height, 0:width]
+    h = (xx.astype(np.uint32) * np.uint32(0x9E3779B1)) ^ (yy.astype(np.uint32) * np.uint32(0x85EBCA77)) ^ np.uint32(seed * 0x27D4EB2F & 0xFFFFFFFF)
+    h ^= h >> np.uint32(15); h *= np.uint32(0x2C1B3C6D); h ^= h >> np.uint32(12)
+    if kind == "checker":
+        c = ((xx // max(1, width // 8)) + (yy // max(1, height // 8))) & 1
+        rgb = np.stack([60 + 150 * c + (h & 31), 200 - 120 * c + ((h >> 5) & 31), 90 + 40 * c + ((h >> 10) & 31)], -1)
+    else:
+        f = 0.5 + 0.25 * np.sin(xx * (6.2831853 * 3 / width)) + 0.25 * np.cos(yy * (6.2831853 * 5 / height))
+        g = np.clip(f * 255.0, 0, 255).astype(np.uint32)
+        rgb = np.stack([g, g, g], -1)
+    return pack_rgba(np.clip(rgb, 0, 255).astype(np.uint8))
+
+
+def textured_scene(small=True, seed=1):
+    """A Sponza-class stand-in for the texture path (tracer.go:468-514): the blob carries a diffuse map with
+    spherical UVs, the ground a bump map with UVs that run outside [0,1) and below 0 (tile(), obj_loader.go:11),
+    the small sphere a diffuse + bump pair, and a second quad a bump map with degenerate UVs (the det < 1e-6
+    fallback of TransformNormalToWorldSpace, renderer.go:229-250)."""
+    level = 3 if small else 5
+    parts, mats, tri_mat, normals, uvs = [], [], [], [], []
+
+    def sph_uv(v, f, center):
+        d = v[f] - np.asarray(center, dtype=F32)                      # [nt,3,3]
+        d = d / np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-9)
+        u = (np.arctan2(d[..., 2], d[..., 0]) / (2 * np.pi) + 0.5).astype(F32)
+        w = (np.arccos(np.clip(d[..., 1], -1, 1)) / np.pi).astype(F32)
+        return np.stack([u, F32(1.0) - w], -1).reshape(-1, 6).astype(F32)     # v = 1 - v (obj_loader.go:92)
+
+    def add(vf, mat_row, uv, smooth=True):
+        v, f = vf
+        parts.append((v, f)); mats.append(mat_row)
+        tri_mat.append(np.full(f.shape[0], len(mats) - 1, dtype=U32))
+        normals.append(corner_normals_smooth(v, f) if smooth else corner_normals_flat(v, f))
+        uvs.append(uv)
+
+    bv, bf = displaced_icosphere(level, seed, radius=1.0, amp=0.3, center=(0.0, 1.05, 0.0))
+    add((bv, bf), material(kd=(0.5, 0.5, 0.5), diffuse_map=1), sph_uv(bv, bf, (0.0, 1.05, 0.0)))
+    qv, qf = quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6))
+    quv = (qv[qf][..., [0, 2]] * F32(0.37) - F32(0.8)).reshape(-1, 6).astype(F32)       # spans about [-3, 1.4]
+    add((qv, qf), material(kd=(0.55, 0.55, 0.55), bump_map=2), quv, smooth=False)
+    sv, sf = icosphere(1 if small else 3)
+    sv = (sv * F32(0.6) + np.array([1.9, 0.6, 0.4], dtype=F32)).astype(F32)
+    add((sv, sf), material(kd=(0.2, 0.2, 0.2), diffuse_map=3, bump_map=2), sph_uv(sv, sf, (1.9, 0.6, 0.4)))
+    wv, wf = quad((-3, 0, -3), (-3, 3, -3), (3, 3, -3), (3, 0, -3))
+    add((wv, wf), material(kd=(0.7, 0.6, 0.5), bump_map=2), np.full((wf.shape[0], 6), 0.25, dtype=F32), smooth=False)
+    v, f = merge(parts)
+    cam = look_at((3.2, 2.4, 5.2), (0.0, 0.8, 0.0), frustum=2.0)
+    tex = [procedural_texture(64, 32, 1, "checker"), procedural_texture(48, 48, 2, "noise"),
+           procedural_texture(17, 9, 3, "checker")]
+    return SceneData(verts=v, tris=f, normals=np.concatenate(normals, 0).astype(F32),
+                     tri_material=np.concatenate(tri_mat).astype(U32), materials=np.stack(mats).astype(F32),
+                     lights=np.stack([_sponza_sun()]).astype(F32), sky=_sponza_sky(), camera=cam,
+                     uvs=np.concatenate(uvs, 0).astype(F32), textures=tex)
 
 
 def blackhole_scene(segments=256):

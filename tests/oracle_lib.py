@@ -166,6 +166,16 @@ def _load_trace():
                                      U16, C.c_int, C.c_int, _F]
     lib.orc_scene_free.restype = None
     lib.orc_scene_free.argtypes = [C.c_void_p]
+    lib.orc_scene_set_textures.restype = None
+    lib.orc_scene_set_textures.argtypes = [C.c_void_p, _F, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _U32]
+    lib.orc_probe_tile.restype = C.c_float
+    lib.orc_probe_tile.argtypes = [C.c_float]
+    lib.orc_probe_texel.restype = C.c_uint32
+    lib.orc_probe_texel.argtypes = [_U32, C.c_int, C.c_int, C.c_float, C.c_float]
+    lib.orc_probe_bump.restype = None
+    lib.orc_probe_bump.argtypes = [_U32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _F]
+    lib.orc_probe_tbn.restype = None
+    lib.orc_probe_tbn.argtypes = [_F, _F, _F, _F, _F]
     lib.orc_render.restype = None
     lib.orc_render.argtypes = [C.c_void_p, _F, C.POINTER(OrcParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                C.c_uint32, _F, _U32, _U64P, C.c_int]
@@ -204,6 +214,14 @@ class OracleScene:
                                            _p(self.lights, C.c_float) if self.lights.size else None,
                                            self.lights.shape[0], _p(self.sky, C.c_float), img_p, iw, ih,
                                            _p(self.bh, C.c_float) if self.bh is not None else None)
+        tex = getattr(sc, "textures", None)
+        if tex and getattr(sc, "uvs", None) is not None:
+            self.uvs = np.ascontiguousarray(sc.uvs, np.float32).reshape(-1, 6)
+            self.tex_w = np.array([t.shape[1] for t in tex], np.int32)
+            self.tex_h = np.array([t.shape[0] for t in tex], np.int32)
+            self.tex_px = np.ascontiguousarray(np.concatenate([np.asarray(t, np.uint32).reshape(-1) for t in tex]))
+            self.lib.orc_scene_set_textures(self.h, _p(self.uvs, C.c_float), len(tex), _p(self.tex_w, C.c_int32),
+                                            _p(self.tex_h, C.c_int32), _p(self.tex_px, C.c_uint32))
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None

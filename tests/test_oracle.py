@@ -123,3 +123,77 @@ def test_generated_scenes_are_reproducible():
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "soup2500_mixed.npz"))
     v, f = scenes.make_soup(2500, 102)
     assert bits_equal(v, g["verts"]) and np.array_equal(f, g["tris"])
+
+
+# ---- textures (obj_loader.go:11-17, renderer.go:122-169, :199-291): hand-derived known answers ----
+
+def _tlib():
+    return oracle_lib._load_trace()
+
+
+def test_tile_wraps_like_modf():
+    lib = _tlib()
+    f = np.float32
+    assert lib.orc_probe_tile(f(0.25)) == f(0.25)
+    assert lib.orc_probe_tile(f(3.75)) == f(0.75)
+    assert lib.orc_probe_tile(f(-0.25)) == f(1) + f(-0.25)          # negative fractions wrap up (obj_loader.go:13-15)
+    assert lib.orc_probe_tile(f(-2.5)) == f(0.5)
+    assert lib.orc_probe_tile(f(2.0)) == f(0.0)
+
+
+def test_sample_diffuse_map_truncates_and_packs():
+    lib = _tlib()
+    img = np.arange(4 * 3, dtype=np.uint32).reshape(3, 4) * np.uint32(0x01020304)       # [h=3, w=4]
+    p = img.ctypes.data_as(oracle_lib._U32)
+    # px = int(x*(W-1)), py = int(y*(H-1))  (renderer.go:123-124): 0.5*3 = 1.5 -> 1; 0.99*2 = 1.98 -> 1
+    assert lib.orc_probe_texel(p, 4, 3, np.float32(0.5), np.float32(0.99)) == img[1, 1]
+    assert lib.orc_probe_texel(p, 4, 3, np.float32(1.0), np.float32(1.0)) == img[2, 3]
+    assert lib.orc_probe_texel(p, 4, 3, np.float32(0.0), np.float32(0.0)) == img[0, 0]
+    # restatement-only clamp (the reference would index out of the slice)
+    assert lib.orc_probe_texel(p, 4, 3, np.float32(np.nan), np.float32(7.0)) == img[2, 0]
+
+
+def test_sample_bump_map_gradient():
+    lib = _tlib()
+    # grey ramp along x: texel (x, y) = 10*x in R,G,B -> height = 10*x/255 * (0.299+0.587+0.114)
+    w, h = 8, 4
+    g = (np.arange(w, dtype=np.uint32) * 10)[None, :].repeat(h, 0)
+    img = np.ascontiguousarray(g | (g << 8) | (g << 16) | np.uint32(0xFF000000))
+    out = np.zeros(3, np.float32)
+    x, y = np.float32(0.4), np.float32(0.4)
+    lib.orc_probe_bump(img.ctypes.data_as(oracle_lib._U32), w, h, x, y, np.float32(1.0), out.ctypes.data_as(oracle_lib._F))
+    f = np.float32
+    def height(px):
+        v = f(10 * px)
+        return f(f(f(f(0.299) * v + f(0.587) * v) + f(0.114) * v) / f(255))
+    pc = int(x * f(w - 1)); pr = int(np.fmod(x + f(1) / f(w), f(1)) * f(w - 1))
+    dx = f(height(pr) - height(pc))                         # up neighbour has the same height: dy = 0
+    n = np.array([-dx, f(-0.0), f(1)], np.float32)
+    ln = f(np.sqrt(f(f(n[0] * n[0] + n[1] * n[1]) + n[2] * n[2])))
+    want = (n * f(f(1) / ln)).astype(np.float32)
+    assert np.array_equal(out, want), (out, want)
+    assert out[0] < 0 and out[2] > 0.9
+
+
+def test_transform_normal_identity_fallback_and_frame():
+    lib = _tlib()
+    F = oracle_lib._F
+    def tbn(tn, wn, abc, uv):
+        a = [np.ascontiguousarray(x, np.float32) for x in (tn, wn, abc, uv)]
+        out = np.zeros(3, np.float32)
+        lib.orc_probe_tbn(*[x.ctypes.data_as(F) for x in a], out.ctypes.data_as(F))
+        return out
+    tri = [0, 0, 0, 1, 0, 0, 0, 0, 1]                       # A, B = +x, C = +z; geometric normal -y / +y
+    wn = [0, 1, 0]
+    # (0,0,1) in tangent space is returned untouched (renderer.go:201-203)
+    assert np.array_equal(tbn([0, 0, 1], wn, tri, [0, 0, 1, 0, 0, 1]), np.float32(wn))
+    # UVs aligned with the edges: tangent = +x, calculated bitangent = n x t = (0,1,0)x(1,0,0) = -z, UV bitangent = +z
+    # -> flipped to +z (renderer.go:273-279); tangent-space (1,0,0) -> +x, (0,1,0) -> +z
+    assert np.allclose(tbn([1, 0, 0], wn, tri, [0, 0, 1, 0, 0, 1]), [1, 0, 0], atol=1e-6)
+    assert np.allclose(tbn([0, 1, 0], wn, tri, [0, 0, 1, 0, 0, 1]), [0, 0, 1], atol=1e-6)
+    # degenerate UVs -> arbitrary frame from up = X because |n.y| >= 0.9 (renderer.go:229-250):
+    # tangent = n x (1,0,0) = (0,0,-1), bitangent = n x tangent = (-1,0,0)
+    assert np.allclose(tbn([1, 0, 0], wn, tri, [0.25] * 6), [0, 0, -1], atol=1e-6)
+    assert np.allclose(tbn([0, 1, 0], wn, tri, [0.25] * 6), [-1, 0, 0], atol=1e-6)
+    got = tbn([0.6, 0, 0.8], wn, tri, [0, 0, 1, 0, 0, 1])
+    assert np.allclose(got, [0.6, 0.8, 0], atol=1e-6) and abs(np.linalg.norm(got) - 1) < 1e-6
