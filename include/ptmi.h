@@ -236,6 +236,30 @@ int ptmi_render_samples(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *p
 int ptmi_to_rgba(ptmi_ctx *ctx, const float *accum_rgb, const uint32_t *counts, int32_t width, int32_t height,
                  uint8_t *rgba);
 
+/* ------------------------------------------------------------------ assets (host only) */
+
+/* Replaces LoadObj (obj_loader.go:19-111, over the vendored decoder obj.go:101-226, :405-939) and the
+ * flattening of DecomposeObjects (renderer.go:293-324) for one object at `position`: parses path and
+ * its material library and yields exactly the arrays ptmi_build_bvh / ptmi_upload_scene /
+ * ptmi_upload_textures take.  Reference behaviour that is kept: only the first object/group of the
+ * file, triangles only, vn and usemtl required, vertices * scale, normals normalised, v -> 1-v,
+ * glass / accretion disk by material name, the grey default material when no .mtl parses.  Where the
+ * reference panics (non-triangle face, missing vn / vt / usemtl, bad index) this returns
+ * PTMI_ERR_INVALID with a message in ptmi_obj_last_error().  Texture files are NOT decoded: their
+ * names come back through ptmi_obj_string and the host decodes them as LoadObj :29-57 does. */
+typedef struct ptmi_obj ptmi_obj;
+int ptmi_obj_load(const char *path, float scale, const float position[3], ptmi_obj **out);
+void ptmi_obj_free(ptmi_obj *obj);
+const char *ptmi_obj_last_error(void);
+int ptmi_obj_sizes(const ptmi_obj *obj, uint64_t *nverts, uint64_t *ntris, uint64_t *nmaterials, int32_t *has_uvs,
+                   uint64_t *nwarnings);
+/* Any pointer may be NULL.  corner_normals: 9 floats per triangle; uvs: 6 per triangle (only when has_uvs). */
+int ptmi_obj_get(const ptmi_obj *obj, float *verts_xyz, uint32_t *tri_idx, float *corner_normals,
+                 uint32_t *tri_material, PtMaterial *materials, float *uvs);
+/* which: 0 material name, 1 map_Kd file, 2 map_Bump file (index = material), 3 warning text (index =
+ * warning number), 4 directory of the .obj.  Owned by obj; "" when absent. */
+const char *ptmi_obj_string(const ptmi_obj *obj, int which, uint64_t index);
+
 #ifdef __cplusplus
 }
 #endif

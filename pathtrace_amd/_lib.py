@@ -86,6 +86,13 @@ SIGNATURES = {
     "ptmi_render_samples": (C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_uint32, C.c_uint32, _F]),
     "ptmi_to_rgba": (C.c_int, [_P, _F, _U32, C.c_int32, C.c_int32, _U8]),
+    "ptmi_obj_load": (C.c_int, [C.c_char_p, C.c_float, _F, C.POINTER(C.c_void_p)]),
+    "ptmi_obj_free": (None, [_P]),
+    "ptmi_obj_last_error": (C.c_char_p, []),
+    "ptmi_obj_sizes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    "ptmi_obj_get": (C.c_int, [_P, _F, _U32, _F, _U32, _P, _F]),
+    "ptmi_obj_string": (C.c_char_p, [_P, C.c_int, C.c_uint64]),
 }
 
 _lib = None

@@ -488,7 +488,6 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
             }
             if (state == ST_SHADOW_DONE) {
                 if (!have_hit) { load_hit(h); have_hit = true; }
-                const PtMaterial &m = sc.mats[h.mat];
                 const V3 albedo = h.albedo;
                 const uint32_t need = FU(F_NEED);
                 V3 direct = mk(0, 0, 0);
