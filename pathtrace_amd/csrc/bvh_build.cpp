@@ -14,13 +14,22 @@
 // Costs, bounds and tie-breaks therefore match the reference bit for bit (tests/test_bvh_build.py
 // checks this against the literal CPU oracle).
 //
+//
+// Parallel form (same bits, any thread count): nodes with many triangles are evaluated
+// and partitioned by all threads -- per-thread bin boxes merged afterwards (min/max folds and counts
+// do not depend on the order), a stable parallel partition -- and every subtree below PAR_NODE
+// triangles is an independent task that builds into its own arrays, spliced back in pre-order.
+//
 // Build flags: -ffp-contract=off (no FMA fusion; Go/amd64 GOAMD64=v1 never fuses).
 #include "bvh_build.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 namespace ptmi {
 namespace {
@@ -72,9 +81,9 @@ inline float split_cost(const FBox &L, const FBox &R) { // bvh.go:201
 }
 
 struct Builder {
-    std::vector<TriInfo> tris;
-    std::vector<uint32_t> ids, tmp;
-    std::vector<uint8_t> kbuf;          // per-triangle bin of the current axis (0..129)
+    const TriInfo *tris = nullptr;      // shared, read-only
+    uint32_t *ids = nullptr, *tmp = nullptr;   // shared; a builder only touches its own [begin, begin+n)
+    uint8_t kbuf[64];                   // per-triangle bin of the current axis (0..129), small nodes only
     LinearBVH *out = nullptr;
     int threshold = 4;
 
@@ -83,7 +92,7 @@ struct Builder {
         nd.is_leaf = 1;
         nd.tri_offset = (uint32_t)out->tri_ids.size();
         nd.tri_count = (uint32_t)n;
-        out->tri_ids.insert(out->tri_ids.end(), ids.begin() + begin, ids.begin() + begin + n);
+        out->tri_ids.insert(out->tri_ids.end(), ids + begin, ids + begin + n);
     }
 
     // Evaluate the 129 candidates of one axis; update best (strict <, in order of i).
@@ -113,7 +122,7 @@ struct Builder {
         std::memset(nonempty, 0, sizeof nonempty);
         if (n <= 48) {
             // small node: no bin boxes, re-scan the (few) triangles per distinct candidate
-            uint8_t *ks = kbuf.data();
+            uint8_t *ks = kbuf;
             for (size_t k = 0; k < n; ++k) {
                 float c = tris[ids[begin + k]].cen[axis];
                 int b = (int)(std::upper_bound(mids, mids + 129, c) - mids);
@@ -174,11 +183,189 @@ struct Builder {
             if (t.cen[best_axis] < best_split) { ids[begin + nl++] = id; grow(L, t); }
             else { tmp[begin + nr++] = id; grow(R, t); }
         }
-        std::copy(tmp.begin() + begin, tmp.begin() + begin + nr, ids.begin() + begin + nl);
+        std::copy(tmp + begin, tmp + begin + nr, ids + begin + nl);
 
         build(begin, nl, L.lo, L.hi, depth - 1, best_cost);
         out->nodes[node].second_child = (uint32_t)out->nodes.size();                                  // linear_bvh.go:102
         build(begin + nl, nr, R.lo, R.hi, depth - 1, best_cost);
+    }
+};
+
+constexpr size_t PAR_NODE = 1u << 17;     // nodes with at least this many triangles are split by all threads
+constexpr size_t TASK_NODE = 1u << 14;    // subtrees below this many triangles are independent tasks
+
+// Run fn(k0, k1, thread) over [0, n) cut into `nthreads` contiguous chunks (chunk t = thread t, so results
+// that are merged in thread order are merged in triangle order).
+template <typename Fn>
+void parallel_for(int nthreads, size_t n, Fn fn) {
+    if (nthreads <= 1 || n < 4096) { fn((size_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    th.reserve(nthreads);
+    for (int t = 0; t < nthreads; ++t) {
+        const size_t k0 = n * (size_t)t / (size_t)nthreads, k1 = n * (size_t)(t + 1) / (size_t)nthreads;
+        th.emplace_back([=]() { fn(k0, k1, t); });
+    }
+    for (std::thread &x : th) x.join();
+}
+
+struct ParallelBuilder {
+    const TriInfo *tris = nullptr;
+    uint32_t *ids = nullptr, *tmp = nullptr;
+    int threshold = 4, nthreads = 1;
+
+    struct TopNode {
+        float lo[3], hi[3];
+        int kind;                  // 0 inner, 1 leaf, 2 task
+        int left = -1, right = -1; // inner
+        size_t begin = 0, n = 0;   // leaf / task
+        int depth = 0; float parent_cost = 0;   // task
+        int task = -1;
+    };
+    std::vector<TopNode> top_nodes;
+    std::vector<int> tasks;                    // top node numbers of kind 2
+    std::vector<LinearBVH> task_out;
+
+    // One axis of bvh.go:167-207 for a big node: every thread bins its chunk, the bin boxes are merged.
+    // Returns false when the mids are not monotone (NaN / overflowing bounds): the caller falls back.
+    bool eval_axis_par(int nthreads, size_t begin, size_t n, int axis, float l, float r, float &best_cost, int &best_axis, float &best_split) {
+        float mids[129];
+        for (int i = 0; i <= 128; ++i) {
+            mids[i] = l + ((r - l) * (float)i) / (float)128;     // bvh.go:172
+            if (i > 0 && !(mids[i] >= mids[i - 1])) return false;
+        }
+        if (mids[0] != mids[0]) return false;
+        std::vector<FBox> tb((size_t)nthreads * 130);
+        parallel_for(nthreads, n, [&](size_t k0, size_t k1, int t) {
+            FBox *bins = tb.data() + (size_t)t * 130;
+            for (size_t k = k0; k < k1; ++k) {
+                const TriInfo &ti = tris[ids[begin + k]];
+                int b = (int)(std::upper_bound(mids, mids + 129, ti.cen[axis]) - mids);
+                grow(bins[b], ti);
+            }
+        });
+        FBox bins[130];
+        for (int t = 0; t < nthreads; ++t)
+            for (int b = 0; b < 130; ++b) merge(bins[b], tb[(size_t)t * 130 + b]);
+        FBox suffix[130];
+        suffix[129] = bins[129];
+        for (int i = 128; i >= 0; --i) { suffix[i] = bins[i]; merge(suffix[i], suffix[i + 1]); }
+        FBox L;
+        for (int i = 0; i <= 128; ++i) {
+            merge(L, bins[i]);
+            if (i > 0 && bins[i].count == 0) continue;
+            float c = split_cost(L, suffix[i + 1]);
+            if (c < best_cost) { best_cost = c; best_axis = axis; best_split = mids[i]; }
+        }
+        return true;
+    }
+
+    int add(const TopNode &t) { top_nodes.push_back(t); return (int)top_nodes.size() - 1; }
+
+    int top(size_t begin, size_t n, const float lo[3], const float hi[3], int depth, float parent_cost) {
+        TopNode t;
+        for (int a = 0; a < 3; ++a) { t.lo[a] = lo[a]; t.hi[a] = hi[a]; }
+        t.begin = begin; t.n = n;
+        if ((int64_t)n <= (int64_t)threshold || depth <= 0) { t.kind = 1; return add(t); }       // bvh.go:153
+        const int nthreads = n >= PAR_NODE ? this->nthreads : 1;     // mid-sized nodes: split inline, children become tasks
+        if (n < TASK_NODE) {
+            t.kind = 2; t.depth = depth; t.parent_cost = parent_cost; t.task = (int)tasks.size();
+            const int id = add(t);
+            tasks.push_back(id);
+            return id;
+        }
+        float best_cost = MAXF, best_split = -1.0f;
+        int best_axis = -1;
+        for (int axis = 0; axis < 3; ++axis) {
+            if (!eval_axis_par(nthreads, begin, n, axis, lo[axis], hi[axis], best_cost, best_axis, best_split)) {
+                Builder b;                                        // literal fallback of the serial builder
+                b.tris = tris; b.ids = ids; b.tmp = tmp; b.threshold = threshold;
+                b.eval_axis(begin, n, axis, lo[axis], hi[axis], best_cost, best_axis, best_split);
+            }
+        }
+        if (best_cost >= parent_cost) { t.kind = 1; return add(t); }                                 // bvh.go:210
+        // getSplit (bvh.go:231-246): stable partition by all threads
+        std::vector<size_t> nl_t(nthreads, 0), nr_t(nthreads, 0);
+        std::vector<FBox> lb(nthreads), rb(nthreads);
+        parallel_for(nthreads, n, [&](size_t k0, size_t k1, int tt) {
+            size_t nl = 0;
+            for (size_t k = k0; k < k1; ++k) nl += tris[ids[begin + k]].cen[best_axis] < best_split ? 1 : 0;
+            nl_t[tt] = nl; nr_t[tt] = (k1 - k0) - nl;
+        });
+        size_t nl = 0, nr = 0;
+        std::vector<size_t> loff(nthreads), roff(nthreads);
+        for (int tt = 0; tt < nthreads; ++tt) { loff[tt] = nl; roff[tt] = nr; nl += nl_t[tt]; nr += nr_t[tt]; }
+        parallel_for(nthreads, n, [&](size_t k0, size_t k1, int tt) {
+            size_t pl = begin + loff[tt], pr = begin + nl + roff[tt];
+            FBox L, R;
+            for (size_t k = k0; k < k1; ++k) {
+                const uint32_t id = ids[begin + k];
+                const TriInfo &ti = tris[id];
+                if (ti.cen[best_axis] < best_split) { tmp[pl++] = id; grow(L, ti); }
+                else { tmp[pr++] = id; grow(R, ti); }
+            }
+            lb[tt] = L; rb[tt] = R;
+        });
+        parallel_for(nthreads, n, [&](size_t k0, size_t k1, int) { std::copy(tmp + begin + k0, tmp + begin + k1, ids + begin + k0); });
+        FBox L, R;
+        for (int tt = 0; tt < nthreads; ++tt) { merge(L, lb[tt]); merge(R, rb[tt]); }
+        t.kind = 0;
+        const int id = add(t);
+        const int l = top(begin, nl, L.lo, L.hi, depth - 1, best_cost);
+        const int r = top(begin + nl, nr, R.lo, R.hi, depth - 1, best_cost);
+        top_nodes[id].left = l; top_nodes[id].right = r;
+        return id;
+    }
+
+    void run_tasks() {
+        task_out.resize(tasks.size());
+        std::vector<int> order(tasks.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return top_nodes[tasks[a]].n > top_nodes[tasks[b]].n; });
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= order.size()) break;
+                const TopNode &t = top_nodes[tasks[order[i]]];
+                Builder b;
+                b.tris = tris; b.ids = ids; b.tmp = tmp; b.threshold = threshold; b.out = &task_out[order[i]];
+                b.out->nodes.reserve(t.n / 2 + 16);
+                b.out->tri_ids.reserve(t.n);
+                b.build(t.begin, t.n, t.lo, t.hi, t.depth, t.parent_cost);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back(worker);
+        for (std::thread &x : th) x.join();
+    }
+
+    // pre-order emission (linear_bvh.go:77-106)
+    void emit(int id, LinearBVH &out) {
+        const TopNode &t = top_nodes[id];
+        if (t.kind == 2) {
+            const LinearBVH &sub = task_out[t.task];
+            const uint32_t nbase = (uint32_t)out.nodes.size(), tbase = (uint32_t)out.tri_ids.size();
+            for (LinNode n : sub.nodes) {
+                if (n.is_leaf) n.tri_offset += tbase; else n.second_child += nbase;
+                out.nodes.push_back(n);
+            }
+            out.tri_ids.insert(out.tri_ids.end(), sub.tri_ids.begin(), sub.tri_ids.end());
+            return;
+        }
+        LinNode nd;
+        std::memset(&nd, 0, sizeof nd);
+        for (int a = 0; a < 3; ++a) { nd.minb[a] = t.lo[a]; nd.maxb[a] = t.hi[a]; }
+        const size_t idx = out.nodes.size();
+        out.nodes.push_back(nd);
+        if (t.kind == 1) {
+            LinNode &l = out.nodes[idx];
+            l.is_leaf = 1; l.tri_offset = (uint32_t)out.tri_ids.size(); l.tri_count = (uint32_t)t.n;
+            out.tri_ids.insert(out.tri_ids.end(), ids + t.begin, ids + t.begin + t.n);
+            return;
+        }
+        emit(t.left, out);
+        out.nodes[idx].second_child = (uint32_t)out.nodes.size();                                      // linear_bvh.go:102
+        emit(t.right, out);
     }
 };
 
@@ -194,30 +381,42 @@ int build_linear_bvh(const float *verts, uint64_t nverts, const uint32_t *tri_id
     for (uint64_t i = 0; i < 3 * ntris; ++i)
         if (tri_idx[i] >= nverts) { *msg = "triangle index out of range"; return -1; }
 
-    Builder b;
-    b.threshold = threshold;
-    b.out = &out;
     out.nodes.clear();
     out.tri_ids.clear();
-    b.tris.resize(ntris);
-    b.ids.resize(ntris);
-    b.tmp.resize(ntris);
-    b.kbuf.resize(64);
-    for (uint64_t k = 0; k < ntris; ++k) {          // bvh.go:250-272
-        const float *a = verts + 3ull * tri_idx[3 * k], *bb = verts + 3ull * tri_idx[3 * k + 1],
-                    *c = verts + 3ull * tri_idx[3 * k + 2];
-        TriInfo &t = b.tris[k];
-        for (int x = 0; x < 3; ++x) {
-            t.cen[x] = ((a[x] + bb[x]) + c[x]) * (float)(1.0 / 3.0);
-            t.mn[x] = gomin(gomin(a[x], bb[x]), c[x]);
-            t.mx[x] = gomax(gomax(a[x], bb[x]), c[x]);
+    std::vector<TriInfo> tris(ntris);
+    std::vector<uint32_t> ids(ntris), tmp(ntris);
+    int nthreads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("PTMI_BUILD_THREADS")) nthreads = std::max(1, std::min(64, atoi(e)));
+    if (ntris < 2 * PAR_NODE) nthreads = 1;
+    parallel_for(nthreads, ntris, [&](size_t k0, size_t k1, int) {
+        for (size_t k = k0; k < k1; ++k) {          // bvh.go:250-272
+            const float *a = verts + 3ull * tri_idx[3 * k], *bb = verts + 3ull * tri_idx[3 * k + 1],
+                        *c = verts + 3ull * tri_idx[3 * k + 2];
+            TriInfo &t = tris[k];
+            for (int x = 0; x < 3; ++x) {
+                t.cen[x] = ((a[x] + bb[x]) + c[x]) * (float)(1.0 / 3.0);
+                t.mn[x] = gomin(gomin(a[x], bb[x]), c[x]);
+                t.mx[x] = gomax(gomax(a[x], bb[x]), c[x]);
+            }
+            ids[k] = (uint32_t)k;
         }
-        b.ids[k] = (uint32_t)k;
+    });
+    const float lo[3] = {bounds[0], bounds[2], bounds[4]}, hi[3] = {bounds[1], bounds[3], bounds[5]};
+    if (nthreads == 1) {
+        Builder b;
+        b.threshold = threshold; b.out = &out; b.tris = tris.data(); b.ids = ids.data(); b.tmp = tmp.data();
+        out.nodes.reserve(ntris / 2 + 16);
+        out.tri_ids.reserve(ntris);
+        b.build(0, ntris, lo, hi, depth, MAXF);
+        return 0;
     }
+    ParallelBuilder pb;
+    pb.tris = tris.data(); pb.ids = ids.data(); pb.tmp = tmp.data(); pb.threshold = threshold; pb.nthreads = nthreads;
+    const int root = pb.top(0, ntris, lo, hi, depth, MAXF);
+    pb.run_tasks();
     out.nodes.reserve(ntris / 2 + 16);
     out.tri_ids.reserve(ntris);
-    const float lo[3] = {bounds[0], bounds[2], bounds[4]}, hi[3] = {bounds[1], bounds[3], bounds[5]};
-    b.build(0, ntris, lo, hi, depth, MAXF);
+    pb.emit(root, out);
     return 0;
 }
 

@@ -89,3 +89,20 @@ def test_error_paths():
     empty = BuildBVH(v, np.zeros((0, 3), np.uint32))
     a = empty.linear()
     assert a.node_bounds.shape[0] == 1 and a.is_leaf[0] == 1 and a.tri_count[0] == 0
+
+
+def test_parallel_builder_is_bit_identical(monkeypatch):
+    """the multi-threaded build (parallel binning + stable parallel partition for big nodes,
+    independent subtree tasks below) gives the same arrays as the serial one, for any thread count."""
+    import time
+    v, f = scenes.make_soup(300_000, seed=5)
+    got = {}
+    for nt in (1, 3, 8):
+        monkeypatch.setenv("PTMI_BUILD_THREADS", str(nt))
+        t0 = time.time()
+        got[nt] = BuildBVH(v, f).linear()
+        print(f"threads {nt}: {time.time() - t0:.2f} s")
+    for nt in (3, 8):
+        for k in ("node_bounds", "is_leaf", "tri_offset", "tri_count", "second_child", "tri_ids"):
+            a, b = getattr(got[1], k), getattr(got[nt], k)
+            assert a.shape == b.shape and a.tobytes() == b.tobytes(), (nt, k)
