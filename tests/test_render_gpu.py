@@ -119,6 +119,24 @@ def test_accumulation_counts_rects_and_counters(gpu_ctx):
     assert np.array_equal(rgba, want) and (rgba[:, 0, :3] == 0).all()
 
 
+def test_frame_loop_writes_frames(gpu_ctx, tmp_path):
+    """driver.frame_loop = main.go:832-941 without the window: 4x4 tiles, PNG per frame, orbiting camera."""
+    from pathtrace_amd import driver
+    from pathtrace_amd.obj import read_image
+    sc = scenes.bunny_scene(small=True)
+    p = make_params(64, 64, bounces=1, seed=9)
+    r = Renderer(sc, ctx=gpu_ctx)
+    lines = []
+    imgs = driver.frame_loop(r, sc, p, frames=2, spp=2, out_dir=str(tmp_path), orbit=(7.0, 0.9, 1.1), log=lines.append)
+    assert len(imgs) == 2 and (tmp_path / "frame1.png").exists() and (tmp_path / "frame2.png").exists()
+    fb = r.render(p, sc.camera, spp=2)                      # frame 1 = the plain 4x4-tile render of the scene camera
+    assert np.array_equal(imgs[0], r.to_rgba(fb))
+    assert not np.array_equal(imgs[0], imgs[1])             # the camera moved
+    packed = read_image(tmp_path / "frame1.png")
+    assert np.array_equal(packed & 0xFF, imgs[0][..., 0])
+    assert sum("rays/s" in l for l in lines) == 32 and any(l.startswith(">>") for l in lines)
+
+
 def test_blackhole_scene(gpu_ctx):
     sc = scenes.blackhole_scene(segments=96)
     p = make_params(32, 32, bounces=1, max_steps=3000, step_size=1.0, seed=2)
