@@ -47,6 +47,7 @@ __device__ __forceinline__ void flush_counters(const TravCounters &c, unsigned l
         vi += __shfl_xor(vi, off); vt += __shfl_xor(vt, off); vl += __shfl_xor(vl, off); va += __shfl_xor(va, off);
     }
     if ((threadIdx.x & 63) == 0) {
+        counters = counter_shard(counters);
         atomicAdd(&counters[CNT_INNER], (unsigned long long)vi);
         atomicAdd(&counters[CNT_TRI], (unsigned long long)vt);
         atomicAdd(&counters[CNT_LEAF], (unsigned long long)vl);
@@ -208,7 +209,7 @@ static void launch_extend(ptmi_ctx *ctx, const float *o, const float *d, const f
     const void *fn = ctx->counting ? (const void *)extend_vote_kernel<STACK, true> : (const void *)extend_vote_kernel<STACK, false>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WAVE, 0) != hipSuccess || per_cu < 1) per_cu = 8;
     per_cu = std::min(per_cu, ctx->persist_waves_per_cu);
-    unsigned long long *cursor = ctx->d_counters + CNT_NEXT_RAY;
+    unsigned long long *cursor = ctx->d_counters + CNT_CURSOR;
     (void)hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s);
     dim3 pgrid((unsigned)std::min<uint64_t>(grid.x, (uint64_t)ctx->num_cus * per_cu));
     if (ctx->counting)
@@ -259,8 +260,8 @@ extern "C" int ptmi_create(int device, ptmi_ctx **out) {
         if (const char *v = getenv("PTMI_VOTE_TRI_BIAS")) ctx->vote_tri_bias = atoi(v);
     }
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
-        (e = hipMalloc((void **)&ctx->d_counters, CNT_WORDS * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMemset(ctx->d_counters, 0, CNT_WORDS * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc((void **)&ctx->d_counters, CNT_TOTAL_WORDS * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(ctx->d_counters, 0, CNT_TOTAL_WORDS * sizeof(unsigned long long))) != hipSuccess) {
         set_err(nullptr, PTMI_ERR_HIP, std::string("ptmi_create: ") + hipGetErrorString(e));
         delete ctx;
         return PTMI_ERR_HIP;
@@ -562,6 +563,20 @@ extern "C" int ptmi_any_hit(ptmi_ctx *ctx, const float *o_xyz, const float *d_xy
 
 // ------------------------------------------------------------------------------------ counters
 
+int ptmi::read_counters(ptmi_ctx *ctx, unsigned long long *h, hipStream_t s) {
+    static_assert(CNT_WORDS * sizeof(unsigned long long) == 128, "a counter shard is one 128-byte line");
+    std::vector<unsigned long long> all((size_t)CNT_SHARDS * CNT_WORDS);
+    PTMI_HIP(ctx, hipMemcpyAsync(all.data(), ctx->d_counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    PTMI_HIP(ctx, hipStreamSynchronize(s));
+    for (int w = 0; w < CNT_WORDS; ++w) h[w] = 0;
+    for (int sh = 0; sh < CNT_SHARDS; ++sh)
+        for (int w = 0; w < CNT_WORDS; ++w) {
+            if (w == CNT_ERROR) h[w] |= all[(size_t)sh * CNT_WORDS + w];
+            else h[w] += all[(size_t)sh * CNT_WORDS + w];
+        }
+    return PTMI_OK;
+}
+
 extern "C" int ptmi_set_counting(ptmi_ctx *ctx, int enabled) {
     if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_set_counting: ctx is null");
     ctx->counting = enabled != 0;
@@ -572,7 +587,7 @@ extern "C" int ptmi_reset_counters(ptmi_ctx *ctx) {
     if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_reset_counters: ctx is null");
     PTMI_HIP(ctx, hipSetDevice(ctx->device));
     PTMI_HIP(ctx, hipDeviceSynchronize());
-    PTMI_HIP(ctx, hipMemset(ctx->d_counters, 0, CNT_WORDS * sizeof(unsigned long long)));
+    PTMI_HIP(ctx, hipMemset(ctx->d_counters, 0, CNT_TOTAL_WORDS * sizeof(unsigned long long)));
     return PTMI_OK;
 }
 
@@ -581,7 +596,8 @@ extern "C" int ptmi_counters(ptmi_ctx *ctx, PtCounters *out) {
     PTMI_HIP(ctx, hipSetDevice(ctx->device));
     PTMI_HIP(ctx, hipDeviceSynchronize());
     unsigned long long h[CNT_WORDS];
-    PTMI_HIP(ctx, hipMemcpy(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    int rc = ptmi::read_counters(ctx, h, nullptr);
+    if (rc) return rc;
     out->closest_queries = h[CNT_CLOSEST]; out->any_queries = h[CNT_ANY]; out->inner_visits = h[CNT_INNER];
     out->tri_tests = h[CNT_TRI]; out->leaf_visits = h[CNT_LEAF]; out->diffuse_events = h[CNT_DIFFUSE];
     out->samples = h[CNT_SAMPLES];

@@ -12,10 +12,19 @@
 // indices into the device counter block (unsigned long long each)
 enum {
     CNT_CLOSEST = 0, CNT_ANY = 1, CNT_INNER = 2, CNT_TRI = 3, CNT_LEAF = 4, CNT_DIFFUSE = 5, CNT_SAMPLES = 6,
-    CNT_NEXT_RAY = 7,      // ray cursor of the persistent extend kernel (reset before each launch)
     CNT_ERROR = 8,         // bit set of integrator self-check failures (ptmi_render.hip: ERR_*), must stay 0
-    CNT_WORDS = 16
+    CNT_WORDS = 16,        // one shard = 16 words = one 128-byte line
+    // Atomics on one line are served one at a time, ~12 ns each, whichever word they address (measured,
+    // tools/ubench_atomic.hip): 20 000 waves adding to one counter block take 0.25 ms for that alone.  The block is
+    // therefore replicated CNT_SHARDS times, a workgroup adds to shard blockIdx % CNT_SHARDS and the host sums.
+    CNT_SHARDS = 64,
+    CNT_CURSOR = CNT_SHARDS * CNT_WORDS,   // ray cursor of the persistent extend kernel: a line of its own
+    CNT_TOTAL_WORDS = (CNT_SHARDS + 1) * CNT_WORDS
 };
+
+__device__ __forceinline__ unsigned long long *counter_shard(unsigned long long *counters) {
+    return counters + (size_t)(blockIdx.x % CNT_SHARDS) * CNT_WORDS;
+}
 
 struct ptmi_ctx {
     int device = 0;
@@ -59,6 +68,8 @@ struct ptmi_ctx {
 };
 
 namespace ptmi {
+// sums the shards of the device counter block into h[CNT_WORDS] (CNT_ERROR is or-ed); synchronises stream s
+int read_counters(ptmi_ctx *ctx, unsigned long long *h, hipStream_t s);
 int set_err(ptmi_ctx *ctx, int code, const std::string &msg);
 int hip_err(ptmi_ctx *ctx, hipError_t e, const char *what);
 int ensure_stage(ptmi_ctx *ctx, size_t bytes);

@@ -42,8 +42,9 @@ enum { FL_SPECULAR = 1, FL_FLIPPED = 2 };
 // what the top frame is waiting for
 enum { PH_EXTEND = 0, PH_REFR_WAIT = 1, PH_SHADOW_WAIT = 2, PH_GI_WAIT = 3, PH_REFL_WAIT = 4 };
 enum { HS_MISS = 0, HS_HIT = 1, HS_HORIZON = 2 };
-// queue counters
-enum { Q_EXT = 0, Q_SHADOW_PATHS = 1, Q_SHADOW_RAYS = 2, Q_FREE = 3, Q_WORDS = 8 };
+// queue counters: each on a 128-byte line of its own (atomics on one line serialise at ~12 ns each whatever word
+// they address), the double-buffered queues with one counter per buffer
+enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHP0 = 2, QC_SHP1 = 3, QC_SRAY = 4, QC_FREE = 5, QC_COUNT = 6, QC_STRIDE = 16 };
 // path header, 16 words = 64 bytes per slot
 enum { H_SID = 0, H_KEY = 1, H_CTR = 2, H_DEPTH = 3, H_TRKLEN = 4, H_HSTATUS = 5, H_HPRIM = 6, H_HT = 7,
        H_VT0 = 8, H_VT1 = 9, H_RO = 10, H_RD = 13, HDRW = 16 };
@@ -83,7 +84,7 @@ struct Pool {
     uint32_t *q_shpath[2];               // paths waiting for their shadow rays
     float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, bits(index into sh))
     uint32_t *q_free;                    // slots that finished in the last shade pass
-    unsigned long long *qcnt;            // Q_WORDS counters
+    unsigned long long *qcnt;            // QC_COUNT counters, QC_STRIDE words apart
     float *out;                          // per-sample radiance [total][3]
 };
 
@@ -109,16 +110,16 @@ __device__ __forceinline__ int32_t f2i(float f) { return __float_as_int(f); }
 // ------------------------------------------------------------------------------------------ generate
 // main.go:861-874 + the TraceRay call of :875 (bounceIndex 0, lastSurfaceNormal {}, not specular,
 // NewRefractiveIndexTracker(1.0), energy 1.0)
+// Every generated path goes to the extend queue, so its queue position needs no atomic: q_ext_next[q_base + i].
 __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, const uint32_t *slots, uint32_t n,
-                                                       uint64_t first_sample, unsigned long long *qcnt_next_ext,
-                                                       uint32_t *q_ext_next) {
+                                                       uint64_t first_sample, uint32_t *q_ext_next, uint32_t q_base) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool live = i < n;
     uint32_t slot = 0;
     if (live) {
         slot = slots ? slots[i] : i;
-        uint64_t sid = first_sample + i;
-        uint32_t pix = (uint32_t)(sid / ra.spp_chunk), s = (uint32_t)(sid % ra.spp_chunk);
+        const uint32_t sid = (uint32_t)first_sample + i;                   // total < 2^32/3 (render_core)
+        uint32_t pix = sid / ra.spp_chunk, s = sid % ra.spp_chunk;
         int X = ra.x0 + (int)(pix % (uint32_t)ra.w), Y = ra.y0 + (int)(pix / (uint32_t)ra.w);
         Rng rng = rng_init(ra.p.seed, (uint32_t)(Y * ra.p.width + X), ra.spp_begin + s);
         float rx = ((float)X + rng_f32(rng)) / (float)ra.p.width;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, c
         V3 rayOrigin = add(add(add(pos, scale(fwd, ra.cam.frustum_distance)), scale(up, py)), scale(right, px));
         V3 d = normalize(mk(rayOrigin.x - pos.x, rayOrigin.y - pos.y, rayOrigin.z - pos.z));
         float4 *h = pl.hdr + (size_t)slot * 4;
-        h[0] = make_float4(u2f((uint32_t)sid), u2f(rng.key), u2f(rng.ctr), i2f(0));
+        h[0] = make_float4(u2f(sid), u2f(rng.key), u2f(rng.ctr), i2f(0));
         h[1] = make_float4(u2f(1u), i2f(HS_MISS), i2f(-1), 0.0f);
         h[2] = make_float4(1.0f, 1.0f, pos.x, pos.y);
         h[3] = make_float4(pos.z, d.x, d.y, d.z);
@@ -139,8 +140,7 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, c
         ((uint32_t *)f)[F_PHASE] = PH_EXTEND;
     }
     // TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0; shade handles that case
-    uint32_t pos_q = wave_append(qcnt_next_ext, live);
-    if (live) q_ext_next[pos_q] = slot;
+    if (live) q_ext_next[q_base + i] = slot;
 }
 
 // ------------------------------------------------------------------------------------------ extend
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
     uint32_t nq = 0;
     if (i < n) {
         uint32_t slot = queue[i];
-        if (slot >= pl.cap) { atomicOr(&counters[CNT_ERROR], (unsigned long long)ERR_SLOT); slot = 0; }
+        if (slot >= pl.cap) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT); slot = 0; }
         float4 *hd = pl.hdr + (size_t)slot * 4;
         const float4 h1 = hd[1], h2 = hd[2], h3 = hd[3];
         V3 o = mk(h2.z, h2.w, h3.x);
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
         hd[3] = make_float4(o.z, d.x, d.y, d.z);
     }
     for (int off = 32; off > 0; off >>= 1) nq += __shfl_xor(nq, off);
-    if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&counters[CNT_CLOSEST], (unsigned long long)nq);
+    if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)nq);
 }
 
 // ------------------------------------------------------------------------------------------ connect
@@ -201,11 +201,11 @@ __global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool p
         bool occ = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, b.x, b.y, b.z, a.w, tc);
         const uint32_t target = f2u(b.w);
         if (target < pl.cap * (uint32_t)pl.nshadow) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = occ ? 1u : 0u;
-        else atomicOr(&counters[CNT_ERROR], (unsigned long long)ERR_SLOT);
+        else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
     }
     if (threadIdx.x == 0) {
         uint32_t cnt = min((uint32_t)WAVE, n - blockIdx.x * WAVE);
-        atomicAdd(&counters[CNT_ANY], (unsigned long long)cnt);
+        atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)cnt);
     }
 }
 
@@ -236,8 +236,10 @@ enum { ST_EXTENDED, ST_MATERIAL, ST_SHADOW_DONE, ST_GI_LOOP, ST_REFL_LOOP, ST_DI
 __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, const uint32_t *list_a,
                                                     uint32_t na, const uint32_t *list_b, uint32_t nb,
                                                     uint32_t *q_ext_next, uint32_t *q_shpath_next,
+                                                    unsigned long long *qc_ext_next, unsigned long long *qc_shp_next,
                                                     unsigned long long *counters) {
     __shared__ float s_fw[FRW * 256];
+    __shared__ uint32_t s_q[4][4];             // [queue][wave]: counts, then bases
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < na + nb;
     uint32_t slot = 0;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
         }
         for (;;) {
             if (err) {      // self-check failed: report, drop the path with zero radiance
-                atomicOr(&counters[CNT_ERROR], (unsigned long long)err);
+                atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)err);
                 float *o = pl.out + 3 * (size_t)(sid < ra.total ? sid : 0);
                 o[0] = o[1] = o[2] = 0.0f;
                 want_extend = want_shadow = false; n_sray = 0; finished = true; break;
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
             }
         }
         if (err && !finished) {
-            atomicOr(&counters[CNT_ERROR], (unsigned long long)err);
+            atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)err);
             want_extend = want_shadow = false; n_sray = 0; finished = true;
         }
         if (!finished) {
@@ -613,27 +615,41 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
 #undef FI_SET
 #undef FU_SET
     }
-    // ---- queue compaction: one atomic per wave and queue ----
-    uint32_t pe = wave_append(&pl.qcnt[Q_WORDS + Q_EXT], want_extend);
-    if (want_extend) q_ext_next[pe] = slot;
-    uint32_t ps = wave_append(&pl.qcnt[Q_WORDS + Q_SHADOW_PATHS], want_shadow);
-    if (want_shadow) q_shpath_next[ps] = slot;
-    uint32_t pf = wave_append(&pl.qcnt[Q_FREE], finished);
-    if (finished) pl.q_free[pf] = slot;
-    // shadow rays: reserve n_sray consecutive entries per lane with a wave-level exclusive scan
+    // ---- queue compaction: one atomic per workgroup and queue (ballot + popcount per wave, 4 waves summed in LDS) ----
     {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const unsigned long long m_ext = __ballot(want_extend), m_shp = __ballot(want_shadow), m_fin = __ballot(finished);
+        // shadow rays: n_sray consecutive entries per lane, wave-level inclusive scan
         uint32_t incl = n_sray;
-        const int lane = threadIdx.x & 63;
         for (int off = 1; off < 64; off <<= 1) {
             uint32_t v = __shfl_up(incl, off);
             if (lane >= off) incl += v;
         }
-        uint32_t total = __shfl(incl, 63);
-        unsigned long long base = 0;
-        if (lane == 63 && total) base = atomicAdd(&pl.qcnt[Q_SHADOW_RAYS], (unsigned long long)total);
-        base = __shfl((long long)base, 63);
+        for (int off = 32; off > 0; off >>= 1) diffuse_events += __shfl_xor(diffuse_events, off);
+        if (lane == 63) {
+            s_q[0][wv] = (uint32_t)__popcll(m_ext); s_q[1][wv] = (uint32_t)__popcll(m_shp);
+            s_q[2][wv] = (uint32_t)__popcll(m_fin); s_q[3][wv] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const int q = threadIdx.x;
+            const uint32_t c0 = s_q[q][0], c1 = s_q[q][1], c2 = s_q[q][2], c3 = s_q[q][3];
+            const uint32_t total = c0 + c1 + c2 + c3;
+            unsigned long long *ctr = q == 0 ? qc_ext_next : q == 1 ? qc_shp_next : q == 2 ? &pl.qcnt[QC_FREE * QC_STRIDE]
+                                                                                          : &pl.qcnt[QC_SRAY * QC_STRIDE];
+            uint32_t base = 0;
+            if (total) base = (uint32_t)atomicAdd(ctr, (unsigned long long)total);
+            s_q[q][0] = base; s_q[q][1] = base + c0; s_q[q][2] = base + c0 + c1; s_q[q][3] = base + c0 + c1 + c2;
+            if (q == 2 && total) atomicAdd(&counter_shard(counters)[CNT_SAMPLES], (unsigned long long)total);
+        }
+        if (lane == 0 && diffuse_events) atomicAdd(&counter_shard(counters)[CNT_DIFFUSE], (unsigned long long)diffuse_events);
+        __syncthreads();
+        if (want_extend) q_ext_next[s_q[0][wv] + (uint32_t)__popcll(m_ext & lt)] = slot;
+        if (want_shadow) q_shpath_next[s_q[1][wv] + (uint32_t)__popcll(m_shp & lt)] = slot;
+        if (finished) pl.q_free[s_q[2][wv] + (uint32_t)__popcll(m_fin & lt)] = slot;
         if (n_sray) {
-            uint32_t pos = (uint32_t)base + (incl - n_sray);
+            uint32_t pos = s_q[3][wv] + (incl - n_sray);
             const float4 *park = pl.park + (size_t)slot * pl.nshadow * 2;
             for (int k = 0; k < pl.nshadow; ++k) {
                 if (!(need_out >> k & 1u)) continue;
@@ -643,13 +659,6 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                 ++pos;
             }
         }
-    }
-    for (int off = 32; off > 0; off >>= 1) diffuse_events += __shfl_xor(diffuse_events, off);
-    uint32_t fin = finished ? 1u : 0u;
-    for (int off = 32; off > 0; off >>= 1) fin += __shfl_xor(fin, off);
-    if ((threadIdx.x & 63) == 0) {
-        if (diffuse_events) atomicAdd(&counters[CNT_DIFFUSE], (unsigned long long)diffuse_events);
-        if (fin) atomicAdd(&counters[CNT_SAMPLES], (unsigned long long)fin);
     }
 }
 
@@ -821,7 +830,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces) {
     size_t o_sh = carve(off, 16 * c * p.nshadow), o_park = carve(off, 32 * c * p.nshadow);
     size_t o_qe0 = carve(off, 4 * c), o_qe1 = carve(off, 4 * c), o_qs0 = carve(off, 4 * c), o_qs1 = carve(off, 4 * c);
     size_t o_ra = carve(off, 16 * c * p.nshadow), o_rb = carve(off, 16 * c * p.nshadow);
-    size_t o_free = carve(off, 4 * c), o_cnt = carve(off, 8 * 2 * Q_WORDS);
+    size_t o_free = carve(off, 4 * c), o_cnt = carve(off, 8 * QC_COUNT * QC_STRIDE);
     PTMI_HIP(ctx, hipMalloc((void **)&rs->pool_mem, off));
     rs->pool_bytes = off;
     char *b = rs->pool_mem;
@@ -894,23 +903,21 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         ra.cam = *cam; ra.p = *prm; ra.x0 = x0; ra.y0 = y0; ra.w = w; ra.h = h;
         ra.spp_begin = spp_begin + done; ra.spp_chunk = chunk; ra.total = npix * chunk;
 
-        // counters: [0..Q_WORDS) = current (Q_FREE lives here), [Q_WORDS..2*Q_WORDS) = "next" queues filled by shade/generate
-        PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, 2 * Q_WORDS * sizeof(unsigned long long), s));
+        const size_t qc_bytes = (size_t)QC_COUNT * QC_STRIDE * sizeof(unsigned long long);
+        auto qc = [&](int which) { return pl.qcnt + (size_t)which * QC_STRIDE; };
         uint64_t next_sample = 0;
         int cur = 0;
         // initial fill
         uint32_t n0 = (uint32_t)std::min<uint64_t>(cap, ra.total);
         hipLaunchKernelGGL(generate_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, pl, ra, (const uint32_t *)nullptr, n0,
-                           next_sample, &pl.qcnt[Q_WORDS + Q_EXT], pl.q_ext[cur]);
+                           next_sample, pl.q_ext[cur], 0u);
         next_sample += n0;
-        unsigned long long hc[2 * Q_WORDS];
-        PTMI_HIP(ctx, hipMemcpyAsync(hc, pl.qcnt, sizeof hc, hipMemcpyDeviceToHost, s));
-        PTMI_HIP(ctx, hipStreamSynchronize(s));
-        uint32_t n_ext = (uint32_t)hc[Q_WORDS + Q_EXT], n_shp = 0, n_srays = 0;
+        unsigned long long hc[QC_COUNT * QC_STRIDE];
+        uint32_t n_ext = n0, n_shp = 0, n_srays = 0;
         uint64_t guard = 0;
         while (n_ext + n_shp > 0) {
             if (++guard > 100000000ull) return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: wavefront loop did not terminate");
-            PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, 2 * Q_WORDS * sizeof(unsigned long long), s));
+            PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, qc_bytes, s));
             if (n_ext) {
                 if (dep <= 16) launch_render_extend<16>(ctx, sc, ra, pl.q_ext[cur], n_ext, s);
                 else if (dep <= 24) launch_render_extend<24>(ctx, sc, ra, pl.q_ext[cur], n_ext, s);
@@ -927,19 +934,20 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             }
             const uint32_t nshade = n_ext + n_shp;
             hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), 0, s, pl, sc, ra, pl.q_ext[cur], n_ext,
-                               pl.q_shpath[cur], n_shp, pl.q_ext[cur ^ 1], pl.q_shpath[cur ^ 1], ctx->d_counters);
+                               pl.q_shpath[cur], n_shp, pl.q_ext[cur ^ 1], pl.q_shpath[cur ^ 1], qc(QC_EXT0 + (cur ^ 1)),
+                               qc(QC_SHP0 + (cur ^ 1)), ctx->d_counters);
             PTMI_HIP(ctx, hipGetLastError());
-            PTMI_HIP(ctx, hipMemcpyAsync(hc, pl.qcnt, sizeof hc, hipMemcpyDeviceToHost, s));
+            PTMI_HIP(ctx, hipMemcpyAsync(hc, pl.qcnt, qc_bytes, hipMemcpyDeviceToHost, s));
             PTMI_HIP(ctx, hipStreamSynchronize(s));
-            uint32_t n_free = (uint32_t)hc[Q_FREE];
-            uint32_t ne = (uint32_t)hc[Q_WORDS + Q_EXT];
-            n_shp = (uint32_t)hc[Q_WORDS + Q_SHADOW_PATHS];
-            n_srays = (uint32_t)hc[Q_SHADOW_RAYS];
+            uint32_t n_free = (uint32_t)hc[QC_FREE * QC_STRIDE];
+            uint32_t ne = (uint32_t)hc[(QC_EXT0 + (cur ^ 1)) * QC_STRIDE];
+            n_shp = (uint32_t)hc[(QC_SHP0 + (cur ^ 1)) * QC_STRIDE];
+            n_srays = (uint32_t)hc[QC_SRAY * QC_STRIDE];
             // re-fill finished slots with fresh samples (appended to the next extend queue)
             if (n_free && next_sample < ra.total) {
                 uint32_t ng = (uint32_t)std::min<uint64_t>(n_free, ra.total - next_sample);
                 hipLaunchKernelGGL(generate_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, pl, ra, (const uint32_t *)pl.q_free,
-                                   ng, next_sample, &pl.qcnt[Q_WORDS + Q_EXT], pl.q_ext[cur ^ 1]);
+                                   ng, next_sample, pl.q_ext[cur ^ 1], ne);
                 next_sample += ng;
                 ne += ng;
             }
@@ -947,11 +955,13 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             cur ^= 1;
         }
         {   // integrator self-checks (ERR_*): any bit set means a path record was corrupt
-            unsigned long long e = 0;
-            PTMI_HIP(ctx, hipMemcpyAsync(&e, ctx->d_counters + CNT_ERROR, sizeof e, hipMemcpyDeviceToHost, s));
-            PTMI_HIP(ctx, hipStreamSynchronize(s));
+            unsigned long long hcnt[CNT_WORDS];
+            int rcc = ptmi::read_counters(ctx, hcnt, s);
+            if (rcc) return rcc;
+            const unsigned long long e = hcnt[CNT_ERROR];
             if (e) {
-                (void)hipMemsetAsync(ctx->d_counters + CNT_ERROR, 0, sizeof e, s);
+                for (int sh = 0; sh < CNT_SHARDS; ++sh)
+                    (void)hipMemsetAsync(ctx->d_counters + (size_t)sh * CNT_WORDS + CNT_ERROR, 0, sizeof e, s);
                 return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: integrator self-check failed, code " + std::to_string(e));
             }
         }
