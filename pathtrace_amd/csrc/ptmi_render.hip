@@ -80,7 +80,8 @@ struct Pool {
     float4 *sh;                          // [cap][nshadow]      (contribution.xyz, occluded as u32 bits)
     float4 *park;                        // [cap][nshadow][2]   a path's shadow rays until the queue reservation
     // queues
-    uint32_t *q_ext[2];                  // extend queue (double buffered)
+    uint32_t *q_ext[2];                  // extend queue (double buffered): slots ...
+    float4 *q_ext_ray[2];                // ... and their rays, 2 x float4 per entry: (o.xyz, bits(slot)) / (d.xyz, -)
     uint32_t *q_shpath[2];               // paths waiting for their shadow rays
     float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, bits(index into sh))
     uint32_t *q_free;                    // slots that finished in the last shade pass
@@ -112,10 +113,12 @@ __device__ __forceinline__ int32_t f2i(float f) { return __float_as_int(f); }
 // NewRefractiveIndexTracker(1.0), energy 1.0)
 // Every generated path goes to the extend queue, so its queue position needs no atomic: q_ext_next[q_base + i].
 __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, const uint32_t *slots, uint32_t n,
-                                                       uint64_t first_sample, uint32_t *q_ext_next, uint32_t q_base) {
+                                                       uint64_t first_sample, uint32_t *q_ext_next, float4 *q_ray_next,
+                                                       uint32_t q_base) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool live = i < n;
     uint32_t slot = 0;
+    V3 gen_o = mk(0, 0, 0), gen_d = mk(0, 0, 0);
     if (live) {
         slot = slots ? slots[i] : i;
         const uint32_t sid = (uint32_t)first_sample + i;                   // total < 2^32/3 (render_core)
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, c
         h[1] = make_float4(u2f(1u), i2f(HS_MISS), i2f(-1), 0.0f);
         h[2] = make_float4(1.0f, 1.0f, pos.x, pos.y);
         h[3] = make_float4(pos.z, d.x, d.y, d.z);
+        gen_o = pos; gen_d = d;
         pl.trk[(size_t)slot * pl.ntrk] = 1.0f;
         float4 *f = pl.fr + (size_t)slot * pl.nframes * 8;
         f[0] = make_float4(i2f(ra.p.bounces), i2f(0), u2f(0u), 1.0f);
@@ -140,38 +144,46 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, c
         ((uint32_t *)f)[F_PHASE] = PH_EXTEND;
     }
     // TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0; shade handles that case
-    if (live) q_ext_next[q_base + i] = slot;
+    if (live) {
+        q_ext_next[q_base + i] = slot;
+        float4 *qr = q_ray_next + 2 * (size_t)(q_base + i);
+        qr[0] = make_float4(gen_o.x, gen_o.y, gen_o.z, u2f(slot));
+        qr[1] = make_float4(gen_d.x, gen_d.y, gen_d.z, 0.0f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ extend
 // The march loop of TraceRay (tracer.go:33-35, 226-256): closest hit on the segment [0, stepSize];
 // on a miss advance (straight) or RK4-step the geodesic (curved) and test the horizon.
-template <int STACK>
+// Queue entries carry the ray, so the kernel reads them coalesced and never reads the (scattered) path header;
+// it writes the hit into the header, and the ray only when the march moved it.
+template <int STACK, bool CURVED>
 __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl, DevScene sc, RenderArgs ra,
-                                                             const uint32_t *queue, uint32_t n,
+                                                             const float4 *__restrict__ qray, uint32_t n,
                                                              unsigned long long *counters) {
     __shared__ uint32_t smem[STACK * WAVE];
     uint32_t i = blockIdx.x * WAVE + threadIdx.x;
     uint32_t nq = 0;
     if (i < n) {
-        uint32_t slot = queue[i];
+        const float4 qa = qray[2 * (size_t)i], qb = qray[2 * (size_t)i + 1];
+        uint32_t slot = f2u(qa.w);
         if (slot >= pl.cap) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT); slot = 0; }
         float4 *hd = pl.hdr + (size_t)slot * 4;
-        const float4 h1 = hd[1], h2 = hd[2], h3 = hd[3];
-        V3 o = mk(h2.z, h2.w, h3.x);
-        V3 d = mk(h3.y, h3.z, h3.w);
-        const bool curved = sc.has_bh != 0;
+        V3 o = mk(qa.x, qa.y, qa.z);
+        V3 d = mk(qb.x, qb.y, qb.z);
         RayState st = {0, 0, 0, 0, 0, 0, 0, 0};
         float vt0 = 1.0f;
-        if (curved) { st = get_initial_state(o, d, sc.bh); vt0 = st.vt; }          // tracer.go:28-31
+        if (CURVED) { st = get_initial_state(o, d, sc.bh); vt0 = st.vt; }          // tracer.go:28-31
         int status = HS_MISS, prim = -1;
         float t = 0.0f;
+        bool moved = false;
         TravCounters tc;
         for (int step = 0; step < ra.p.max_steps; ++step) {
             ++nq;
             closest_hit<WAVE, false>(bvh, smem + threadIdx.x, o.x, o.y, o.z, d.x, d.y, d.z, ra.p.step_size, prim, t, tc);
             if (prim >= 0) { status = HS_HIT; break; }
-            if (!curved) {
+            moved = true;
+            if (!CURVED) {
                 o = add(o, scale(d, ra.p.step_size));                              // :226-228
             } else {
                 st = rk4_step(st, ra.p.step_size, sc.bh.rs);                       // :231
@@ -181,9 +193,12 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
                 if (dot(rel, rel) <= sc.bh.rs * sc.bh.rs) { status = HS_HORIZON; break; }   // :250-255
             }
         }
-        hd[1] = make_float4(h1.x, i2f(status), i2f(prim), t);
-        hd[2] = make_float4(vt0, st.vt, o.x, o.y);
-        hd[3] = make_float4(o.z, d.x, d.y, d.z);
+        float *h1 = (float *)(hd + 1);                                             // word 0 (tracker length) is shade's
+        h1[1] = i2f(status); h1[2] = i2f(prim); h1[3] = t;
+        if (CURVED || moved) {
+            hd[2] = make_float4(vt0, st.vt, o.x, o.y);
+            hd[3] = make_float4(o.z, d.x, d.y, d.z);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) nq += __shfl_xor(nq, off);
     if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)nq);
@@ -208,6 +223,7 @@ __global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool p
         atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)cnt);
     }
 }
+
 
 // ------------------------------------------------------------------------------------------ shade
 
@@ -235,7 +251,7 @@ enum { ST_EXTENDED, ST_MATERIAL, ST_SHADOW_DONE, ST_GI_LOOP, ST_REFL_LOOP, ST_DI
 
 __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, const uint32_t *list_a,
                                                     uint32_t na, const uint32_t *list_b, uint32_t nb,
-                                                    uint32_t *q_ext_next, uint32_t *q_shpath_next,
+                                                    uint32_t *q_ext_next, float4 *q_ray_next, uint32_t *q_shpath_next,
                                                     unsigned long long *qc_ext_next, unsigned long long *qc_shp_next,
                                                     unsigned long long *counters) {
     __shared__ float s_fw[FRW * 256];
@@ -247,6 +263,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
     uint32_t n_sray = 0;                       // shadow rays this path wants to enqueue
     uint32_t need_out = 0;                     // their slots (bit k = shadow slot k)
     uint32_t diffuse_events = 0;
+    V3 out_o = mk(0, 0, 0), out_d = mk(0, 0, 0);   // the ray of a path that wants an extend (goes into its queue entry)
     if (live) {
         slot = i < na ? list_a[i] : list_b[i - na];
         uint32_t err = 0;
@@ -605,6 +622,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
             if (want_extend) {
                 hd[2] = make_float4(h2.x, h2.y, cur_o.x, cur_o.y);
                 hd[3] = make_float4(cur_o.z, cur_d.x, cur_d.y, cur_d.z);
+                out_o = cur_o; out_d = cur_d;
             }
         }
 #undef FW
@@ -645,7 +663,12 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
         }
         if (lane == 0 && diffuse_events) atomicAdd(&counter_shard(counters)[CNT_DIFFUSE], (unsigned long long)diffuse_events);
         __syncthreads();
-        if (want_extend) q_ext_next[s_q[0][wv] + (uint32_t)__popcll(m_ext & lt)] = slot;
+        if (want_extend) {
+            const uint32_t pe = s_q[0][wv] + (uint32_t)__popcll(m_ext & lt);
+            q_ext_next[pe] = slot;
+            q_ray_next[2 * (size_t)pe] = make_float4(out_o.x, out_o.y, out_o.z, u2f(slot));
+            q_ray_next[2 * (size_t)pe + 1] = make_float4(out_d.x, out_d.y, out_d.z, 0.0f);
+        }
         if (want_shadow) q_shpath_next[s_q[1][wv] + (uint32_t)__popcll(m_shp & lt)] = slot;
         if (finished) pl.q_free[s_q[2][wv] + (uint32_t)__popcll(m_fin & lt)] = slot;
         if (n_sray) {
@@ -830,6 +853,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces) {
     size_t o_sh = carve(off, 16 * c * p.nshadow), o_park = carve(off, 32 * c * p.nshadow);
     size_t o_qe0 = carve(off, 4 * c), o_qe1 = carve(off, 4 * c), o_qs0 = carve(off, 4 * c), o_qs1 = carve(off, 4 * c);
     size_t o_ra = carve(off, 16 * c * p.nshadow), o_rb = carve(off, 16 * c * p.nshadow);
+    size_t o_qr0 = carve(off, 32 * c), o_qr1 = carve(off, 32 * c);
     size_t o_free = carve(off, 4 * c), o_cnt = carve(off, 8 * QC_COUNT * QC_STRIDE);
     PTMI_HIP(ctx, hipMalloc((void **)&rs->pool_mem, off));
     rs->pool_bytes = off;
@@ -837,6 +861,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces) {
     p.hdr = (float4 *)(b + o_hdr); p.fr = (float4 *)(b + o_fr); p.trk = (float *)(b + o_trk);
     p.sh = (float4 *)(b + o_sh); p.park = (float4 *)(b + o_park);
     p.q_ext[0] = (uint32_t *)(b + o_qe0); p.q_ext[1] = (uint32_t *)(b + o_qe1);
+    p.q_ext_ray[0] = (float4 *)(b + o_qr0); p.q_ext_ray[1] = (float4 *)(b + o_qr1);
     p.q_shpath[0] = (uint32_t *)(b + o_qs0); p.q_shpath[1] = (uint32_t *)(b + o_qs1);
     p.q_sray_a = (float4 *)(b + o_ra); p.q_sray_b = (float4 *)(b + o_rb);
     p.q_free = (uint32_t *)(b + o_free); p.qcnt = (unsigned long long *)(b + o_cnt);
@@ -846,9 +871,14 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces) {
 }
 
 template <int STACK>
-static void launch_render_extend(ptmi_ctx *ctx, const DevScene &sc, const RenderArgs &ra, const uint32_t *q, uint32_t n, hipStream_t s) {
-    hipLaunchKernelGGL((render_extend_kernel<STACK>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
-                       ctx->render->pool, sc, ra, q, n, ctx->d_counters);
+static void launch_render_extend(ptmi_ctx *ctx, const DevScene &sc, const RenderArgs &ra, const float4 *qray, uint32_t n,
+                                 hipStream_t s) {
+    if (sc.has_bh)
+        hipLaunchKernelGGL((render_extend_kernel<STACK, true>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
+                           ctx->render->pool, sc, ra, qray, n, ctx->d_counters);
+    else
+        hipLaunchKernelGGL((render_extend_kernel<STACK, false>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
+                           ctx->render->pool, sc, ra, qray, n, ctx->d_counters);
 }
 template <int STACK>
 static void launch_render_connect(ptmi_ctx *ctx, uint32_t n, hipStream_t s) {
@@ -910,7 +940,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         // initial fill
         uint32_t n0 = (uint32_t)std::min<uint64_t>(cap, ra.total);
         hipLaunchKernelGGL(generate_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, pl, ra, (const uint32_t *)nullptr, n0,
-                           next_sample, pl.q_ext[cur], 0u);
+                           next_sample, pl.q_ext[cur], pl.q_ext_ray[cur], 0u);
         next_sample += n0;
         unsigned long long hc[QC_COUNT * QC_STRIDE];
         uint32_t n_ext = n0, n_shp = 0, n_srays = 0;
@@ -919,11 +949,11 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             if (++guard > 100000000ull) return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: wavefront loop did not terminate");
             PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, qc_bytes, s));
             if (n_ext) {
-                if (dep <= 16) launch_render_extend<16>(ctx, sc, ra, pl.q_ext[cur], n_ext, s);
-                else if (dep <= 24) launch_render_extend<24>(ctx, sc, ra, pl.q_ext[cur], n_ext, s);
-                else if (dep <= 32) launch_render_extend<32>(ctx, sc, ra, pl.q_ext[cur], n_ext, s);
-                else if (dep <= 48) launch_render_extend<48>(ctx, sc, ra, pl.q_ext[cur], n_ext, s);
-                else launch_render_extend<64>(ctx, sc, ra, pl.q_ext[cur], n_ext, s);
+                if (dep <= 16) launch_render_extend<16>(ctx, sc, ra, pl.q_ext_ray[cur], n_ext, s);
+                else if (dep <= 24) launch_render_extend<24>(ctx, sc, ra, pl.q_ext_ray[cur], n_ext, s);
+                else if (dep <= 32) launch_render_extend<32>(ctx, sc, ra, pl.q_ext_ray[cur], n_ext, s);
+                else if (dep <= 48) launch_render_extend<48>(ctx, sc, ra, pl.q_ext_ray[cur], n_ext, s);
+                else launch_render_extend<64>(ctx, sc, ra, pl.q_ext_ray[cur], n_ext, s);
             }
             if (n_srays) {
                 if (dep <= 16) launch_render_connect<16>(ctx, n_srays, s);
@@ -934,7 +964,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             }
             const uint32_t nshade = n_ext + n_shp;
             hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), 0, s, pl, sc, ra, pl.q_ext[cur], n_ext,
-                               pl.q_shpath[cur], n_shp, pl.q_ext[cur ^ 1], pl.q_shpath[cur ^ 1], qc(QC_EXT0 + (cur ^ 1)),
+                               pl.q_shpath[cur], n_shp, pl.q_ext[cur ^ 1], pl.q_ext_ray[cur ^ 1], pl.q_shpath[cur ^ 1], qc(QC_EXT0 + (cur ^ 1)),
                                qc(QC_SHP0 + (cur ^ 1)), ctx->d_counters);
             PTMI_HIP(ctx, hipGetLastError());
             PTMI_HIP(ctx, hipMemcpyAsync(hc, pl.qcnt, qc_bytes, hipMemcpyDeviceToHost, s));
@@ -947,7 +977,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             if (n_free && next_sample < ra.total) {
                 uint32_t ng = (uint32_t)std::min<uint64_t>(n_free, ra.total - next_sample);
                 hipLaunchKernelGGL(generate_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, pl, ra, (const uint32_t *)pl.q_free,
-                                   ng, next_sample, pl.q_ext[cur ^ 1], ne);
+                                   ng, next_sample, pl.q_ext[cur ^ 1], pl.q_ext_ray[cur ^ 1], ne);
                 next_sample += ng;
                 ne += ng;
             }

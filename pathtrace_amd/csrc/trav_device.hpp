@@ -114,13 +114,27 @@ struct LdsStack {
     __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
 
+__device__ __forceinline__ float slab_fast(float minx, float miny, float minz, float maxx, float maxy, float maxz,
+                                           float ox, float oy, float oz, float ix, float iy, float iz, float step);
+__device__ __forceinline__ bool finitef(float x) { return fabsf(x) <= PT_INF; }   // false for NaN and +-Inf
+// true when the ray must take the NaN-exact slab (see slab_fast below)
+__device__ __forceinline__ bool ray_needs_exact(const DevBVH &bvh, float ox, float oy, float oz, float ix, float iy, float iz,
+                                                float step) {
+    return !(finitef(ix) && finitef(iy) && finitef(iz) && finitef(ox) && finitef(oy) && finitef(oz) && finitef(step)) ||
+           !bvh.bounds_finite;
+}
+template <bool EXACT>
+__device__ __forceinline__ float slab_sel(float minx, float miny, float minz, float maxx, float maxy, float maxz,
+                                          float ox, float oy, float oz, float ix, float iy, float iz, float step) {
+    return EXACT ? slab(minx, miny, minz, maxx, maxy, maxz, ox, oy, oz, ix, iy, iz, step)
+                 : slab_fast(minx, miny, minz, maxx, maxy, maxz, ox, oy, oz, ix, iy, iz, step);
+}
+
 // CheckIntersection (linear_bvh.go:116-170).  prim = -1 on a miss.
-template <int BLOCK, bool COUNT>
-__device__ __forceinline__ void closest_hit(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
-                                            float dx, float dy, float dz, float step, int &prim_out, float &t_out,
-                                            TravCounters &cnt) {
-    // Inverse() (vec3.go:118-124); the reference recomputes it per box with the same result
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+template <int BLOCK, bool COUNT, bool EXACT>
+__device__ __forceinline__ void closest_hit_impl(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
+                                                 float dx, float dy, float dz, float ix, float iy, float iz, float step,
+                                                 int &prim_out, float &t_out, TravCounters &cnt) {
     LdsStack<BLOCK> st{stack_base};
     float best_t = step;
     int best = -1;
@@ -130,8 +144,8 @@ __device__ __forceinline__ void closest_hit(const DevBVH &bvh, uint32_t *stack_b
             if (COUNT) cnt.inner++;
             const float4 *p = bvh.nodes + (size_t)cur * 4;
             const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-            float d1 = slab(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, best_t);
-            float d2 = slab(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, best_t);
+            float d1 = slab_sel<EXACT>(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, best_t);
+            float d2 = slab_sel<EXACT>(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, best_t);
             uint32_t i = __float_as_uint(q3.x), j = __float_as_uint(q3.y);
             if (d1 > d2) { uint32_t ti = i; i = j; j = ti; float td = d1; d1 = d2; d2 = td; }   // :148-151
             if (d1 == PT_INF) {                                                                  // :152-154
@@ -163,6 +177,18 @@ __device__ __forceinline__ void closest_hit(const DevBVH &bvh, uint32_t *stack_b
     }
     prim_out = best;
     t_out = best >= 0 ? best_t : 0.0f;
+}
+// The walk takes the cheaper NaN-free slab when no active lane of the wave needs the exact one.
+template <int BLOCK, bool COUNT>
+__device__ __forceinline__ void closest_hit(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
+                                            float dx, float dy, float dz, float step, int &prim_out, float &t_out,
+                                            TravCounters &cnt) {
+    // Inverse() (vec3.go:118-124); the reference recomputes it per box with the same result
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    if (__any(ray_needs_exact(bvh, ox, oy, oz, ix, iy, iz, step)))
+        closest_hit_impl<BLOCK, COUNT, true>(bvh, stack_base, ox, oy, oz, dx, dy, dz, ix, iy, iz, step, prim_out, t_out, cnt);
+    else
+        closest_hit_impl<BLOCK, COUNT, false>(bvh, stack_base, ox, oy, oz, dx, dy, dz, ix, iy, iz, step, prim_out, t_out, cnt);
 }
 
 // ---- step-wise form of the same walk (used by the persistent kernel) --------------------------------
@@ -203,15 +229,12 @@ struct RayTrav {
     bool exact;          // needs the NaN-exact slab
 };
 
-__device__ __forceinline__ bool finitef(float x) { return fabsf(x) <= PT_INF; }   // false for NaN and +-Inf
-
 __device__ __forceinline__ void trav_init(RayTrav &r, const DevBVH &bvh, float ox, float oy, float oz, float dx, float dy,
                                           float dz, float step) {
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
     r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;        // Inverse() (vec3.go:118-124)
     r.best_t = step; r.best = -1; r.cur = bvh.root_ref; r.sp = 0;
-    r.exact = !(finitef(r.ix) && finitef(r.iy) && finitef(r.iz) && finitef(ox) && finitef(oy) && finitef(oz) &&
-                finitef(step)) || !bvh.bounds_finite;
+    r.exact = ray_needs_exact(bvh, ox, oy, oz, r.ix, r.iy, r.iz, step);
 }
 
 // ---- single-step forms for the vote-scheduled kernel -------------------------------------------------
@@ -297,11 +320,71 @@ __device__ __forceinline__ void vote_tri_step(const DevBVH &bvh, uint32_t *stack
     }
 }
 
-// QuickCheckIntersection (linear_bvh.go:202-250)
+// ---- any-hit forms of the two steps (QuickCheckIntersection, linear_bvh.go:202-250) -------------------
+// r.best_t holds the (constant) range, r.best becomes 1 when an occluder is found and the walk stops.
+
+// linear_bvh.go:218-246 for one inner node
+template <int BLOCK, bool COUNT, bool EXACT>
+__device__ __forceinline__ void vote_inner_step_any(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
+    if (COUNT) cnt.inner++;
+    const float4 *p = bvh.nodes + (size_t)r.cur * 4;
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    const float step = r.best_t;
+    float d1, d2;
+    if (EXACT) {
+        d1 = slab(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, step);
+        d2 = slab(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, step);
+    } else {
+        slab_fast2(q0, q1, q2, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, step, d1, d2);
+    }
+    const uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
+    const bool h1 = d1 < step, h2 = d2 < step;
+    if (h1 && h2) {                                                 // :226-238 far child pushed first, near on top
+        const bool first_near = d1 < d2;
+        stack_base[r.sp * BLOCK] = first_near ? r1 : r0; ++r.sp;
+        r.cur = first_near ? r0 : r1;
+    } else if (h1 || h2) {                                          // :239-244
+        r.cur = h1 ? r0 : r1;
+    } else {
+        r.cur = trav_pop<BLOCK>(stack_base, r.sp);
+    }
+}
+
+// One triangle of a leaf with FastIntersectShadowTriangle (linear_bvh.go:173-200): the early returns become one
+// predicate evaluated in the source's order (a NaN fails each compare as it does there; the three quotients
+// are only looked at when |a| >= 1e-5).
 template <int BLOCK, bool COUNT>
-__device__ __forceinline__ bool any_hit(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
-                                        float dx, float dy, float dz, float step, TravCounters &cnt) {
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+__device__ __forceinline__ void vote_tri_step_any(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
+    const uint32_t rec = r.cur & 0x7FFFFFFFu;
+    const float4 *p = bvh.tris + (size_t)rec * 3;
+    const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+    const float ax = r1.z, ay = r1.w, az = r2.x;
+    const float e1x = r0.x - ax, e1y = r0.z - ay, e1z = r1.x - az;
+    const float e2x = r0.y - ax, e2y = r0.w - ay, e2z = r1.y - az;
+    const float hx = r.dy * e2z - r.dz * e2y, hy = r.dz * e2x - r.dx * e2z, hz = r.dx * e2y - r.dy * e2x;
+    const float a = (e1x * hx + e1y * hy) + e1z * hz;
+    const float sx = r.ox - ax, sy = r.oy - ay, sz = r.oz - az;
+    const float u = ((sx * hx + sy * hy) + sz * hz) / a;
+    const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;
+    const float v = ((r.dx * qx + r.dy * qy) + r.dz * qz) / a;
+    const float t = ((e2x * qx + e2y * qy) + e2z * qz) / a;
+    bool hit = !(fabsf(a) < (float)0.00001);
+    hit = hit && !(u < 0.0f || u > 1.0f);
+    hit = hit && !(v < 0.0f || u + v > 1.0f);
+    hit = hit && (t > (float)0.00001 && t < r.best_t);
+    if (COUNT) { if (rec != bvh.dummy_tri) cnt.tri++; }
+    const bool last = __float_as_uint(r2.z) == 0u;
+    if (COUNT) { if (last || hit) cnt.leaf++; }
+    if (hit) { r.best = 1; r.sp = 0; r.cur = D_REF_DONE; }
+    else if (last) r.cur = trav_pop<BLOCK>(stack_base, r.sp);
+    else r.cur = r.cur + 1u;
+}
+
+// QuickCheckIntersection (linear_bvh.go:202-250)
+template <int BLOCK, bool COUNT, bool EXACT>
+__device__ __forceinline__ bool any_hit_impl(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
+                                             float dx, float dy, float dz, float ix, float iy, float iz, float step,
+                                             TravCounters &cnt) {
     LdsStack<BLOCK> st{stack_base};
     uint32_t cur = bvh.root_ref;
     for (;;) {
@@ -309,8 +392,8 @@ __device__ __forceinline__ bool any_hit(const DevBVH &bvh, uint32_t *stack_base,
             if (COUNT) cnt.inner++;
             const float4 *p = bvh.nodes + (size_t)cur * 4;
             const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-            float d1 = slab(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, step);
-            float d2 = slab(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, step);
+            float d1 = slab_sel<EXACT>(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, step);
+            float d2 = slab_sel<EXACT>(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, step);
             uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
             bool h1 = d1 < step, h2 = d2 < step;
             if (h1 && h2) {                              // :226-238 push far first, near on top
@@ -339,6 +422,14 @@ __device__ __forceinline__ bool any_hit(const DevBVH &bvh, uint32_t *stack_base,
         if (st.empty()) return false;
         cur = st.pop();
     }
+}
+template <int BLOCK, bool COUNT>
+__device__ __forceinline__ bool any_hit(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
+                                        float dx, float dy, float dz, float step, TravCounters &cnt) {
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    if (__any(ray_needs_exact(bvh, ox, oy, oz, ix, iy, iz, step)))
+        return any_hit_impl<BLOCK, COUNT, true>(bvh, stack_base, ox, oy, oz, dx, dy, dz, ix, iy, iz, step, cnt);
+    return any_hit_impl<BLOCK, COUNT, false>(bvh, stack_base, ox, oy, oz, dx, dy, dz, ix, iy, iz, step, cnt);
 }
 
 }  // namespace ptmi
