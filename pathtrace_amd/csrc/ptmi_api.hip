@@ -91,7 +91,8 @@ __global__ __launch_bounds__(WAVE) void extend_vote_kernel(DevBVH bvh, const flo
                                                            const float *__restrict__ tmax, uint64_t n,
                                                            int32_t *__restrict__ prim, float *__restrict__ t,
                                                            unsigned long long *counters,
-                                                           unsigned long long *cursor, int refill_min, int tri_bias) {
+                                                           unsigned long long *cursor, int refill_min, int tri_bias,
+                                                           uint32_t chunk_rays) {
     __shared__ uint32_t smem[STACK * WAVE];
     uint32_t *stack_base = smem + threadIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(WAVE) void extend_vote_kernel(DevBVH bvh, const flo
     // chunk pipeline (wave-uniform): `chunk` is being handed out, `chunk1` is ready, `inflight` (lane 0) is on its way
     auto grab = [&]() -> unsigned long long {
         unsigned long long v = 0;
-        if (lane == 0) v = atomicAdd(cursor, (unsigned long long)WAVE);
+        if (lane == 0) v = atomicAdd(cursor, (unsigned long long)chunk_rays);
         return v;
     };
     auto uniform = [&](unsigned long long v) -> uint64_t {
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(WAVE) void extend_vote_kernel(DevBVH bvh, const flo
     unsigned long long inflight = grab();
     uint32_t used = 0;                      // rays of `chunk` already reserved
     auto reserve = [&](uint32_t k) {        // k-th ray counted from the start of `chunk` -> prefetch registers
-        const uint64_t idx = k < (uint32_t)WAVE ? chunk + k : chunk1 + (k - WAVE);
+        const uint64_t idx = k < chunk_rays ? chunk + k : chunk1 + (k - chunk_rays);
         have_next = idx < n;
         if (have_next) {
             next_ray = idx;
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(WAVE) void extend_vote_kernel(DevBVH bvh, const flo
     };
     auto advance = [&](uint32_t taken) {
         used += taken;
-        if (used >= (uint32_t)WAVE) {
-            used -= WAVE;
+        if (used >= chunk_rays) {
+            used -= chunk_rays;
             chunk = chunk1;
             chunk1 = uniform(inflight);
             inflight = grab();
@@ -214,10 +215,10 @@ static void launch_extend(ptmi_ctx *ctx, const float *o, const float *d, const f
     dim3 pgrid((unsigned)std::min<uint64_t>(grid.x, (uint64_t)ctx->num_cus * per_cu));
     if (ctx->counting)
         hipLaunchKernelGGL((extend_vote_kernel<STACK, true>), pgrid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t,
-                           ctx->d_counters, cursor, ctx->vote_refill_min, ctx->vote_tri_bias);
+                           ctx->d_counters, cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
     else
         hipLaunchKernelGGL((extend_vote_kernel<STACK, false>), pgrid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t,
-                           ctx->d_counters, cursor, ctx->vote_refill_min, ctx->vote_tri_bias);
+                           ctx->d_counters, cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
 }
 template <int STACK>
 static void launch_connect(ptmi_ctx *ctx, const float *o, const float *d, const float *tmax, uint64_t n, uint8_t *occ,
@@ -258,6 +259,8 @@ extern "C" int ptmi_create(int device, ptmi_ctx **out) {
         if (const char *v = getenv("PTMI_PERSIST_WAVES_PER_CU")) ctx->persist_waves_per_cu = std::max(1, atoi(v));
         if (const char *v = getenv("PTMI_VOTE_REFILL_MIN")) ctx->vote_refill_min = std::max(1, std::min(64, atoi(v)));
         if (const char *v = getenv("PTMI_VOTE_TRI_BIAS")) ctx->vote_tri_bias = atoi(v);
+        if (const char *v = getenv("PTMI_RENDER_LANES")) ctx->render_lanes = atoi(v);
+        if (const char *v = getenv("PTMI_VOTE_CHUNK")) ctx->vote_chunk = std::max(64, atoi(v) / 64 * 64);
     }
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
         (e = hipMalloc((void **)&ctx->d_counters, CNT_TOTAL_WORDS * sizeof(unsigned long long))) != hipSuccess ||

@@ -57,8 +57,10 @@ struct ptmi_ctx {
     int extend_variant = 1;
     int persist_waves_per_cu = 32;      // upper bound; the launch takes min(this, what the LDS stacks allow)
     int num_cus = 256;
+    int render_lanes = 1;               // path pools worked side by side (2 = pipelined lanes: measured 7 % slower, shade fills the VGPR file)
     int vote_refill_min = 16;           // refill once this many lanes are idle
     int vote_tri_bias = -8;             // inner step wins the vote when nI + bias >= nT
+    int vote_chunk = 128;               // rays reserved per cursor atomic (multiple of 64)
 
     // work counters
     bool counting = false;

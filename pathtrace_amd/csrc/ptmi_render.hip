@@ -714,8 +714,11 @@ struct RenderState {
     PtBlackHole bh{}; int has_bh = 0;
     // pool (device), sized for (cap, bounces, nlights)
     char *pool_mem = nullptr; size_t pool_bytes = 0;
-    uint32_t pool_cap = 0; int pool_bounces = -2, pool_nlights = -1;
-    Pool pool{};
+    uint32_t pool_cap = 0; int pool_bounces = -2, pool_nlights = -1, pool_lanes = 0;
+    Pool pools[2]{};                     // one per lane (render_core)
+    hipStream_t lane_stream = nullptr;   // lane 1 runs here, lane 0 on the caller's stream
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_trav[2] = {nullptr, nullptr};
+    unsigned long long *h_qc = nullptr;  // pinned, 2 x QC_COUNT * QC_STRIDE words
     float *d_out = nullptr; size_t out_bytes = 0;
     float *d_accum = nullptr; uint32_t *d_counts = nullptr; size_t accum_pix = 0;
 };
@@ -727,6 +730,11 @@ void free_scene(ptmi_ctx *ctx) {
     void *ptrs[] = {rs->d_uvs, rs->d_tex, rs->d_tex_pixels, rs->d_stri, rs->d_mats, rs->d_emissive, rs->d_lights,
                     rs->d_sky_img, rs->pool_mem, rs->d_out, rs->d_accum, rs->d_counts};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (rs->lane_stream) (void)hipStreamDestroy(rs->lane_stream);
+    if (rs->ev_begin) (void)hipEventDestroy(rs->ev_begin);
+    if (rs->ev_end) (void)hipEventDestroy(rs->ev_end);
+    for (hipEvent_t e : rs->ev_trav) if (e) (void)hipEventDestroy(e);
+    if (rs->h_qc) (void)hipHostFree(rs->h_qc);
     delete rs;
     ctx->render = nullptr;
 }
@@ -835,55 +843,142 @@ static size_t carve(size_t &off, size_t bytes) {
     return o;
 }
 
-static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces) {
+static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     RenderState *rs = ctx->render;
-    if (rs->pool_mem && rs->pool_cap == cap && rs->pool_bounces == bounces && rs->pool_nlights == (int)rs->nlights)
+    if (rs->pool_mem && rs->pool_cap == cap && rs->pool_bounces == bounces && rs->pool_nlights == (int)rs->nlights &&
+        rs->pool_lanes == lanes)
         return PTMI_OK;
     if (rs->pool_mem) { (void)hipFree(rs->pool_mem); rs->pool_mem = nullptr; }
-    Pool p{};
-    p.cap = cap;
-    p.nframes = bounces + 1; p.nshadow = (int)rs->nlights + 2;
+    const int nframes = bounces + 1, nshadow = (int)rs->nlights + 2;
     // every TraceRay invocation can push one index and the sibling subtrees share the tracker, so its history is
     // bounded by the number of invocations, 2^(bounces+1)-1 (capped at 64 entries, like the oracle)
-    p.ntrk = bounces + 1 >= 6 ? 64 : (1 << (bounces + 1)) + 1;
-    p.ntrk = (p.ntrk + 3) / 4 * 4;
-    size_t off = 0;
+    int ntrk = bounces + 1 >= 6 ? 64 : (1 << (bounces + 1)) + 1;
+    ntrk = (ntrk + 3) / 4 * 4;
     const size_t c = cap;
-    size_t o_hdr = carve(off, 64 * c), o_fr = carve(off, 128 * c * (size_t)p.nframes), o_trk = carve(off, 4 * c * p.ntrk);
-    size_t o_sh = carve(off, 16 * c * p.nshadow), o_park = carve(off, 32 * c * p.nshadow);
-    size_t o_qe0 = carve(off, 4 * c), o_qe1 = carve(off, 4 * c), o_qs0 = carve(off, 4 * c), o_qs1 = carve(off, 4 * c);
-    size_t o_ra = carve(off, 16 * c * p.nshadow), o_rb = carve(off, 16 * c * p.nshadow);
-    size_t o_qr0 = carve(off, 32 * c), o_qr1 = carve(off, 32 * c);
-    size_t o_free = carve(off, 4 * c), o_cnt = carve(off, 8 * QC_COUNT * QC_STRIDE);
+    struct Off { size_t hdr, fr, trk, sh, park, qe0, qe1, qs0, qs1, ra, rb, qr0, qr1, free_, cnt; } of[2];
+    size_t off = 0;
+    for (int l = 0; l < lanes; ++l) {
+        Off &o = of[l];
+        o.hdr = carve(off, 64 * c); o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
+        o.sh = carve(off, 16 * c * nshadow); o.park = carve(off, 32 * c * nshadow);
+        o.qe0 = carve(off, 4 * c); o.qe1 = carve(off, 4 * c); o.qs0 = carve(off, 4 * c); o.qs1 = carve(off, 4 * c);
+        o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow);
+        o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
+        o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * QC_COUNT * QC_STRIDE);
+    }
     PTMI_HIP(ctx, hipMalloc((void **)&rs->pool_mem, off));
     rs->pool_bytes = off;
     char *b = rs->pool_mem;
-    p.hdr = (float4 *)(b + o_hdr); p.fr = (float4 *)(b + o_fr); p.trk = (float *)(b + o_trk);
-    p.sh = (float4 *)(b + o_sh); p.park = (float4 *)(b + o_park);
-    p.q_ext[0] = (uint32_t *)(b + o_qe0); p.q_ext[1] = (uint32_t *)(b + o_qe1);
-    p.q_ext_ray[0] = (float4 *)(b + o_qr0); p.q_ext_ray[1] = (float4 *)(b + o_qr1);
-    p.q_shpath[0] = (uint32_t *)(b + o_qs0); p.q_shpath[1] = (uint32_t *)(b + o_qs1);
-    p.q_sray_a = (float4 *)(b + o_ra); p.q_sray_b = (float4 *)(b + o_rb);
-    p.q_free = (uint32_t *)(b + o_free); p.qcnt = (unsigned long long *)(b + o_cnt);
-    rs->pool = p;
-    rs->pool_cap = cap; rs->pool_bounces = bounces; rs->pool_nlights = (int)rs->nlights;
+    for (int l = 0; l < lanes; ++l) {
+        const Off &o = of[l];
+        Pool p{};
+        p.cap = cap; p.nframes = nframes; p.nshadow = nshadow; p.ntrk = ntrk;
+        p.hdr = (float4 *)(b + o.hdr); p.fr = (float4 *)(b + o.fr); p.trk = (float *)(b + o.trk);
+        p.sh = (float4 *)(b + o.sh); p.park = (float4 *)(b + o.park);
+        p.q_ext[0] = (uint32_t *)(b + o.qe0); p.q_ext[1] = (uint32_t *)(b + o.qe1);
+        p.q_ext_ray[0] = (float4 *)(b + o.qr0); p.q_ext_ray[1] = (float4 *)(b + o.qr1);
+        p.q_shpath[0] = (uint32_t *)(b + o.qs0); p.q_shpath[1] = (uint32_t *)(b + o.qs1);
+        p.q_sray_a = (float4 *)(b + o.ra); p.q_sray_b = (float4 *)(b + o.rb);
+        p.q_free = (uint32_t *)(b + o.free_); p.qcnt = (unsigned long long *)(b + o.cnt);
+        rs->pools[l] = p;
+    }
+    rs->pool_cap = cap; rs->pool_bounces = bounces; rs->pool_nlights = (int)rs->nlights; rs->pool_lanes = lanes;
     return PTMI_OK;
 }
 
 template <int STACK>
-static void launch_render_extend(ptmi_ctx *ctx, const DevScene &sc, const RenderArgs &ra, const float4 *qray, uint32_t n,
-                                 hipStream_t s) {
+static void launch_render_extend_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, const float4 *qray,
+                                   uint32_t n, hipStream_t s) {
     if (sc.has_bh)
         hipLaunchKernelGGL((render_extend_kernel<STACK, true>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
-                           ctx->render->pool, sc, ra, qray, n, ctx->d_counters);
+                           pl, sc, ra, qray, n, ctx->d_counters);
     else
         hipLaunchKernelGGL((render_extend_kernel<STACK, false>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
-                           ctx->render->pool, sc, ra, qray, n, ctx->d_counters);
+                           pl, sc, ra, qray, n, ctx->d_counters);
+}
+static void launch_render_extend(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, const float4 *qray,
+                                 uint32_t n, hipStream_t s) {
+    const int dep = ctx->max_depth;      // the LDS stack is as deep as the tree
+    if (dep <= 16) launch_render_extend_t<16>(ctx, pl, sc, ra, qray, n, s);
+    else if (dep <= 24) launch_render_extend_t<24>(ctx, pl, sc, ra, qray, n, s);
+    else if (dep <= 32) launch_render_extend_t<32>(ctx, pl, sc, ra, qray, n, s);
+    else if (dep <= 48) launch_render_extend_t<48>(ctx, pl, sc, ra, qray, n, s);
+    else launch_render_extend_t<64>(ctx, pl, sc, ra, qray, n, s);
 }
 template <int STACK>
-static void launch_render_connect(ptmi_ctx *ctx, uint32_t n, hipStream_t s) {
-    hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
-                       ctx->render->pool, n, ctx->d_counters);
+static void launch_render_connect_t(ptmi_ctx *ctx, const Pool &pl, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n,
+                       ctx->d_counters);
+}
+static void launch_render_connect(ptmi_ctx *ctx, const Pool &pl, uint32_t n, hipStream_t s) {
+    const int dep = ctx->max_depth;
+    if (dep <= 16) launch_render_connect_t<16>(ctx, pl, n, s);
+    else if (dep <= 24) launch_render_connect_t<24>(ctx, pl, n, s);
+    else if (dep <= 32) launch_render_connect_t<32>(ctx, pl, n, s);
+    else if (dep <= 48) launch_render_connect_t<48>(ctx, pl, n, s);
+    else launch_render_connect_t<64>(ctx, pl, n, s);
+}
+
+// One lane = one path pool with its queues, working through its own range of sample ids on its own stream.
+// Two lanes run side by side, half an iteration apart: shade waits on memory most of the time (2 waves per SIMD,
+// ~25 % VALU busy) while extend and connect are VALU-bound, so a lane's traversal kernels wait (event) for the
+// other lane's traversal kernels and run under the other lane's shade.  The image does not depend on the split
+// (a sample's RNG stream is keyed by pixel and sample number).
+struct Lane {
+    Pool pl;
+    hipStream_t st = nullptr;
+    uint64_t next_sample = 0, end_sample = 0;
+    int cur = 0;
+    uint32_t n_ext = 0, n_shp = 0, n_srays = 0;
+    bool inflight = false;
+    hipEvent_t ev_trav = nullptr;        // recorded after this lane's extend + connect
+    bool ev_recorded = false;
+    unsigned long long *hc = nullptr;    // pinned host copy of the queue counters (a pageable copy would block the host)
+};
+
+static int lane_enqueue(ptmi_ctx *ctx, Lane &L, Lane *other, const DevScene &sc, const RenderArgs &ra) {
+    Pool &pl = L.pl;
+    const size_t qc_bytes = (size_t)QC_COUNT * QC_STRIDE * sizeof(unsigned long long);
+    auto qc = [&](int which) { return pl.qcnt + (size_t)which * QC_STRIDE; };
+    const int cur = L.cur;
+    PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, qc_bytes, L.st));
+    if (other && other->ev_recorded) PTMI_HIP(ctx, hipStreamWaitEvent(L.st, other->ev_trav, 0));
+    if (L.n_ext) launch_render_extend(ctx, pl, sc, ra, pl.q_ext_ray[cur], L.n_ext, L.st);
+    if (L.n_srays) launch_render_connect(ctx, pl, L.n_srays, L.st);
+    if (other) { PTMI_HIP(ctx, hipEventRecord(L.ev_trav, L.st)); L.ev_recorded = true; }
+    const uint32_t nshade = L.n_ext + L.n_shp;
+    hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), 0, L.st, pl, sc, ra, pl.q_ext[cur], L.n_ext,
+                       pl.q_shpath[cur], L.n_shp, pl.q_ext[cur ^ 1], pl.q_ext_ray[cur ^ 1], pl.q_shpath[cur ^ 1],
+                       qc(QC_EXT0 + (cur ^ 1)), qc(QC_SHP0 + (cur ^ 1)), ctx->d_counters);
+    PTMI_HIP(ctx, hipGetLastError());
+    PTMI_HIP(ctx, hipMemcpyAsync(L.hc, pl.qcnt, qc_bytes, hipMemcpyDeviceToHost, L.st));
+    L.inflight = true;
+    return PTMI_OK;
+}
+
+// waits for the lane's iteration, reads its queue counts and re-fills finished slots with fresh samples
+static int lane_finish(ptmi_ctx *ctx, Lane &L, const RenderArgs &ra) {
+    Pool &pl = L.pl;
+    PTMI_HIP(ctx, hipStreamSynchronize(L.st));
+    L.inflight = false;
+    const int nxt = L.cur ^ 1;
+    const uint32_t n_free = (uint32_t)L.hc[QC_FREE * QC_STRIDE];
+    uint32_t ne = (uint32_t)L.hc[(QC_EXT0 + nxt) * QC_STRIDE];
+    L.n_shp = (uint32_t)L.hc[(QC_SHP0 + nxt) * QC_STRIDE];
+    L.n_srays = (uint32_t)L.hc[QC_SRAY * QC_STRIDE];
+    if (ne > pl.cap || L.n_shp > pl.cap || n_free > pl.cap || L.n_srays > pl.cap * (uint32_t)pl.nshadow)
+        return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: queue counter out of range");
+    if (n_free && L.next_sample < L.end_sample) {
+        const uint32_t ng = (uint32_t)std::min<uint64_t>(n_free, L.end_sample - L.next_sample);
+        hipLaunchKernelGGL(generate_kernel, dim3((ng + 255) / 256), dim3(256), 0, L.st, pl, ra, (const uint32_t *)pl.q_free, ng,
+                           L.next_sample, pl.q_ext[nxt], pl.q_ext_ray[nxt], ne);
+        PTMI_HIP(ctx, hipGetLastError());
+        L.next_sample += ng;
+        ne += ng;
+    }
+    L.n_ext = ne;
+    L.cur = nxt;
+    return PTMI_OK;
 }
 
 // Renders samples [spp_begin, spp_begin+spp_count) of the rectangle into d_out chunks and accumulates them
@@ -907,17 +1002,24 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     // samples per pixel per batch: bound the per-sample output buffer (<= ~3 GiB, < 2^32/3 samples)
     uint32_t spp_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp_count, (256ull << 20) / npix));
     const uint64_t max_total = npix * spp_chunk;
-    uint32_t cap = (uint32_t)std::min<uint64_t>(max_total, 1u << 21);
+    // two lanes of 2^20 paths when there is enough work to keep both busy, else one
+    const int lanes = (ctx->render_lanes >= 2 && max_total >= (1ull << 18)) ? 2 : 1;
+    uint32_t cap = (uint32_t)std::min<uint64_t>((max_total + lanes - 1) / lanes, (1u << 21) / (uint32_t)lanes);
     cap = (cap + 255) / 256 * 256;
-    int rc = ensure_pool(ctx, cap, bounces);
+    int rc = ensure_pool(ctx, cap, bounces, lanes);
     if (rc) return rc;
     if (rs->out_bytes < max_total * 12) {
         if (rs->d_out) { (void)hipFree(rs->d_out); rs->d_out = nullptr; }
         PTMI_HIP(ctx, hipMalloc((void **)&rs->d_out, max_total * 12));
         rs->out_bytes = max_total * 12;
     }
-    Pool &pl = rs->pool;
-    pl.out = rs->d_out;
+    if (!rs->lane_stream) {
+        PTMI_HIP(ctx, hipStreamCreateWithFlags(&rs->lane_stream, hipStreamNonBlocking));
+        PTMI_HIP(ctx, hipEventCreateWithFlags(&rs->ev_begin, hipEventDisableTiming));
+        PTMI_HIP(ctx, hipEventCreateWithFlags(&rs->ev_end, hipEventDisableTiming));
+        for (hipEvent_t &e : rs->ev_trav) PTMI_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        PTMI_HIP(ctx, hipHostMalloc((void **)&rs->h_qc, 2 * QC_COUNT * QC_STRIDE * sizeof(unsigned long long), hipHostMallocDefault));
+    }
 
     DevScene sc{};
     sc.uvs = rs->d_uvs; sc.tex = rs->d_tex; sc.tex_pixels = rs->d_tex_pixels; sc.ntex = rs->ntex;
@@ -926,63 +1028,51 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     sc.lights = rs->d_lights; sc.nlights = rs->nlights; sc.sky = rs->sky; sc.sky_img = rs->d_sky_img;
     sc.bh = rs->bh; sc.has_bh = rs->has_bh;
 
-    const int dep = ctx->max_depth;
     for (uint32_t done = 0; done < spp_count; done += spp_chunk) {
         const uint32_t chunk = std::min(spp_chunk, spp_count - done);
         RenderArgs ra{};
         ra.cam = *cam; ra.p = *prm; ra.x0 = x0; ra.y0 = y0; ra.w = w; ra.h = h;
         ra.spp_begin = spp_begin + done; ra.spp_chunk = chunk; ra.total = npix * chunk;
 
-        const size_t qc_bytes = (size_t)QC_COUNT * QC_STRIDE * sizeof(unsigned long long);
-        auto qc = [&](int which) { return pl.qcnt + (size_t)which * QC_STRIDE; };
-        uint64_t next_sample = 0;
-        int cur = 0;
-        // initial fill
-        uint32_t n0 = (uint32_t)std::min<uint64_t>(cap, ra.total);
-        hipLaunchKernelGGL(generate_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, pl, ra, (const uint32_t *)nullptr, n0,
-                           next_sample, pl.q_ext[cur], pl.q_ext_ray[cur], 0u);
-        next_sample += n0;
-        unsigned long long hc[QC_COUNT * QC_STRIDE];
-        uint32_t n_ext = n0, n_shp = 0, n_srays = 0;
+        // lane 1's stream joins the caller's stream here and hands back at the end of the chunk
+        if (lanes > 1) {
+            PTMI_HIP(ctx, hipEventRecord(rs->ev_begin, s));
+            PTMI_HIP(ctx, hipStreamWaitEvent(rs->lane_stream, rs->ev_begin, 0));
+        }
+        Lane L[2];
+        const uint64_t half = lanes > 1 ? (ra.total + 1) / 2 : ra.total;
+        for (int l = 0; l < lanes; ++l) {
+            L[l].pl = rs->pools[l];
+            L[l].pl.out = rs->d_out;
+            L[l].st = l == 0 ? s : rs->lane_stream;
+            L[l].hc = rs->h_qc + (size_t)l * QC_COUNT * QC_STRIDE;
+            L[l].ev_trav = rs->ev_trav[l];
+            L[l].next_sample = l == 0 ? 0 : half;
+            L[l].end_sample = l == 0 ? half : ra.total;
+            // initial fill
+            const uint32_t n0 = (uint32_t)std::min<uint64_t>(cap, L[l].end_sample - L[l].next_sample);
+            if (n0) {
+                hipLaunchKernelGGL(generate_kernel, dim3((n0 + 255) / 256), dim3(256), 0, L[l].st, L[l].pl, ra,
+                                   (const uint32_t *)nullptr, n0, L[l].next_sample, L[l].pl.q_ext[0], L[l].pl.q_ext_ray[0], 0u);
+                PTMI_HIP(ctx, hipGetLastError());
+            }
+            L[l].next_sample += n0;
+            L[l].n_ext = n0;
+        }
+        for (int l = 0; l < lanes; ++l)
+            if (L[l].n_ext + L[l].n_shp > 0 && (rc = lane_enqueue(ctx, L[l], lanes > 1 ? &L[l ^ 1] : nullptr, sc, ra))) return rc;
         uint64_t guard = 0;
-        while (n_ext + n_shp > 0) {
+        while (L[0].inflight || (lanes > 1 && L[1].inflight)) {
             if (++guard > 100000000ull) return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: wavefront loop did not terminate");
-            PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, qc_bytes, s));
-            if (n_ext) {
-                if (dep <= 16) launch_render_extend<16>(ctx, sc, ra, pl.q_ext_ray[cur], n_ext, s);
-                else if (dep <= 24) launch_render_extend<24>(ctx, sc, ra, pl.q_ext_ray[cur], n_ext, s);
-                else if (dep <= 32) launch_render_extend<32>(ctx, sc, ra, pl.q_ext_ray[cur], n_ext, s);
-                else if (dep <= 48) launch_render_extend<48>(ctx, sc, ra, pl.q_ext_ray[cur], n_ext, s);
-                else launch_render_extend<64>(ctx, sc, ra, pl.q_ext_ray[cur], n_ext, s);
+            for (int l = 0; l < lanes; ++l) {
+                if (!L[l].inflight) continue;
+                if ((rc = lane_finish(ctx, L[l], ra))) return rc;
+                if (L[l].n_ext + L[l].n_shp > 0 && (rc = lane_enqueue(ctx, L[l], lanes > 1 ? &L[l ^ 1] : nullptr, sc, ra))) return rc;
             }
-            if (n_srays) {
-                if (dep <= 16) launch_render_connect<16>(ctx, n_srays, s);
-                else if (dep <= 24) launch_render_connect<24>(ctx, n_srays, s);
-                else if (dep <= 32) launch_render_connect<32>(ctx, n_srays, s);
-                else if (dep <= 48) launch_render_connect<48>(ctx, n_srays, s);
-                else launch_render_connect<64>(ctx, n_srays, s);
-            }
-            const uint32_t nshade = n_ext + n_shp;
-            hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), 0, s, pl, sc, ra, pl.q_ext[cur], n_ext,
-                               pl.q_shpath[cur], n_shp, pl.q_ext[cur ^ 1], pl.q_ext_ray[cur ^ 1], pl.q_shpath[cur ^ 1], qc(QC_EXT0 + (cur ^ 1)),
-                               qc(QC_SHP0 + (cur ^ 1)), ctx->d_counters);
-            PTMI_HIP(ctx, hipGetLastError());
-            PTMI_HIP(ctx, hipMemcpyAsync(hc, pl.qcnt, qc_bytes, hipMemcpyDeviceToHost, s));
-            PTMI_HIP(ctx, hipStreamSynchronize(s));
-            uint32_t n_free = (uint32_t)hc[QC_FREE * QC_STRIDE];
-            uint32_t ne = (uint32_t)hc[(QC_EXT0 + (cur ^ 1)) * QC_STRIDE];
-            n_shp = (uint32_t)hc[(QC_SHP0 + (cur ^ 1)) * QC_STRIDE];
-            n_srays = (uint32_t)hc[QC_SRAY * QC_STRIDE];
-            // re-fill finished slots with fresh samples (appended to the next extend queue)
-            if (n_free && next_sample < ra.total) {
-                uint32_t ng = (uint32_t)std::min<uint64_t>(n_free, ra.total - next_sample);
-                hipLaunchKernelGGL(generate_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, pl, ra, (const uint32_t *)pl.q_free,
-                                   ng, next_sample, pl.q_ext[cur ^ 1], pl.q_ext_ray[cur ^ 1], ne);
-                next_sample += ng;
-                ne += ng;
-            }
-            n_ext = ne;
-            cur ^= 1;
+        }
+        if (lanes > 1) {
+            PTMI_HIP(ctx, hipEventRecord(rs->ev_end, rs->lane_stream));
+            PTMI_HIP(ctx, hipStreamWaitEvent(s, rs->ev_end, 0));
         }
         {   // integrator self-checks (ERR_*): any bit set means a path record was corrupt
             unsigned long long hcnt[CNT_WORDS];
