@@ -281,7 +281,7 @@ def main():
                          "tri_tests_per_ray": round(c.tri_tests / n, 3),
                          "note": "the 67 MB tree is cache resident (traffic = fabric bytes from profiles/), so frac "
                                  "can exceed 1; the ceiling this kernel runs against is the CU's L1 gather rate, "
-                                 "13.9 TB/s chip-wide measured by tools/ubench_gather.hip (profiles/r01b)",
+                                 "13.9 TB/s chip-wide measured by tools/ubench_gather.hip (profiles/r01b/ubench_gather.txt)",
                          "l1_gather_peak_GBs": L1_GATHER_PEAK_GBS,
                          "frac_of_l1_gather_peak": round(achieved / L1_GATHER_PEAK_GBS, 4)},
         }

@@ -44,7 +44,12 @@ enum { PH_EXTEND = 0, PH_REFR_WAIT = 1, PH_SHADOW_WAIT = 2, PH_GI_WAIT = 3, PH_R
 enum { HS_MISS = 0, HS_HIT = 1, HS_HORIZON = 2 };
 // queue counters: each on a 128-byte line of its own (atomics on one line serialise at ~12 ns each whatever word
 // they address), the double-buffered queues with one counter per buffer
-enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHP0 = 2, QC_SHP1 = 3, QC_SRAY = 4, QC_FREE = 5, QC_COUNT = 6, QC_STRIDE = 16 };
+// Shadow rays are queued by kind (bucket 0 = sky sample, 1.. = light i, then the emissive-triangle sample; kinds
+// beyond NSB-1 share the last bucket): a wave of the connect kernel then holds rays of one kind, which have similar
+// directions and lengths, instead of a mix in which the short ones idle until the longest has finished.
+enum { NSB = 8 };
+enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHP0 = 2, QC_SHP1 = 3, QC_FREE = 4, QC_SRAY = 5, QC_COUNT = QC_SRAY + NSB, QC_STRIDE = 16 };
+struct ShadowCounts { uint32_t n[NSB]; };
 // path header, 16 words = 64 bytes per slot
 enum { H_SID = 0, H_KEY = 1, H_CTR = 2, H_DEPTH = 3, H_TRKLEN = 4, H_HSTATUS = 5, H_HPRIM = 6, H_HT = 7,
        H_VT0 = 8, H_VT1 = 9, H_RO = 10, H_RD = 13, HDRW = 16 };
@@ -205,25 +210,33 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
 }
 
 // ------------------------------------------------------------------------------------------ connect
+// Bucket b's rays sit at q_sray[b * cap ...]; workgroups are dealt to the buckets in order.
 template <int STACK>
-__global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool pl, uint32_t n,
+__global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool pl, ShadowCounts sn,
                                                               unsigned long long *counters) {
     __shared__ uint32_t smem[STACK * WAVE];
-    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
-    if (i < n) {
-        const float4 a = pl.q_sray_a[i], b = pl.q_sray_b[i];
+    uint32_t blk = blockIdx.x, b = 0, n = 0;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < NSB; ++k) {          // unrolled: the counts stay in scalar registers
+        const uint32_t nb = (sn.n[k] + WAVE - 1) / WAVE;
+        if (!found) { if (blk < nb) { b = k; n = sn.n[k]; found = true; } else blk -= nb; }
+    }
+    const uint32_t j = blk * WAVE + threadIdx.x;
+    if (j < n) {
+        const size_t i = (size_t)b * pl.cap + j;
+        const float4 a = pl.q_sray_a[i], bb = pl.q_sray_b[i];
         TravCounters tc;
-        bool occ = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, b.x, b.y, b.z, a.w, tc);
-        const uint32_t target = f2u(b.w);
+        bool occ = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc);
+        const uint32_t target = f2u(bb.w);
         if (target < pl.cap * (uint32_t)pl.nshadow) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = occ ? 1u : 0u;
         else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
     }
-    if (threadIdx.x == 0) {
-        uint32_t cnt = min((uint32_t)WAVE, n - blockIdx.x * WAVE);
+    if (threadIdx.x == 0 && blk * WAVE < n) {
+        uint32_t cnt = min((uint32_t)WAVE, n - blk * WAVE);
         atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)cnt);
     }
 }
-
 
 // ------------------------------------------------------------------------------------------ shade
 
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
                                                     unsigned long long *qc_ext_next, unsigned long long *qc_shp_next,
                                                     unsigned long long *counters) {
     __shared__ float s_fw[FRW * 256];
-    __shared__ uint32_t s_q[4][4];             // [queue][wave]: counts, then bases
+    __shared__ uint32_t s_q[3 + NSB][4];       // [queue][wave]: counts, then bases (ext, shadow paths, free, NSB ray buckets)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < na + nb;
     uint32_t slot = 0;
@@ -638,24 +651,32 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         const unsigned long long lt = (1ull << lane) - 1ull;
         const unsigned long long m_ext = __ballot(want_extend), m_shp = __ballot(want_shadow), m_fin = __ballot(finished);
-        // shadow rays: n_sray consecutive entries per lane, wave-level inclusive scan
-        uint32_t incl = n_sray;
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
+        // shadow rays by bucket: kinds 0 .. NSB-2 are one ray per lane at most (ballot), the last bucket can take several
+        const uint32_t last_bits = need_out >> (NSB - 1);
+        uint32_t incl = (uint32_t)__popc(last_bits);
+        if (pl.nshadow >= NSB) {
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
         }
+        unsigned long long m_ray[NSB - 1];
+#pragma unroll
+        for (int b = 0; b < NSB - 1; ++b) m_ray[b] = __ballot((need_out >> b) & 1u);
         for (int off = 32; off > 0; off >>= 1) diffuse_events += __shfl_xor(diffuse_events, off);
         if (lane == 63) {
             s_q[0][wv] = (uint32_t)__popcll(m_ext); s_q[1][wv] = (uint32_t)__popcll(m_shp);
-            s_q[2][wv] = (uint32_t)__popcll(m_fin); s_q[3][wv] = incl;
+            s_q[2][wv] = (uint32_t)__popcll(m_fin);
+#pragma unroll
+            for (int b = 0; b < NSB - 1; ++b) s_q[3 + b][wv] = (uint32_t)__popcll(m_ray[b]);
+            s_q[3 + NSB - 1][wv] = pl.nshadow >= NSB ? incl : 0u;
         }
         __syncthreads();
-        if (threadIdx.x < 4) {
+        if (threadIdx.x < 3 + NSB) {
             const int q = threadIdx.x;
             const uint32_t c0 = s_q[q][0], c1 = s_q[q][1], c2 = s_q[q][2], c3 = s_q[q][3];
             const uint32_t total = c0 + c1 + c2 + c3;
-            unsigned long long *ctr = q == 0 ? qc_ext_next : q == 1 ? qc_shp_next : q == 2 ? &pl.qcnt[QC_FREE * QC_STRIDE]
-                                                                                          : &pl.qcnt[QC_SRAY * QC_STRIDE];
+            unsigned long long *ctr = q == 0 ? qc_ext_next : q == 1 ? qc_shp_next : &pl.qcnt[(size_t)(QC_FREE + (q - 2)) * QC_STRIDE];
             uint32_t base = 0;
             if (total) base = (uint32_t)atomicAdd(ctr, (unsigned long long)total);
             s_q[q][0] = base; s_q[q][1] = base + c0; s_q[q][2] = base + c0 + c1; s_q[q][3] = base + c0 + c1 + c2;
@@ -672,14 +693,24 @@ __global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, Render
         if (want_shadow) q_shpath_next[s_q[1][wv] + (uint32_t)__popcll(m_shp & lt)] = slot;
         if (finished) pl.q_free[s_q[2][wv] + (uint32_t)__popcll(m_fin & lt)] = slot;
         if (n_sray) {
-            uint32_t pos = s_q[3][wv] + (incl - n_sray);
             const float4 *park = pl.park + (size_t)slot * pl.nshadow * 2;
+            uint32_t pos_last = s_q[3 + NSB - 1][wv] + (incl - (uint32_t)__popc(last_bits));
             for (int k = 0; k < pl.nshadow; ++k) {
                 if (!(need_out >> k & 1u)) continue;
-                float4 a = park[2 * k], b = park[2 * k + 1];
-                b.w = u2f(slot * (uint32_t)pl.nshadow + (uint32_t)k);
-                pl.q_sray_a[pos] = a; pl.q_sray_b[pos] = b;
-                ++pos;
+                uint32_t pos;
+                if (k < NSB - 1) {
+                    unsigned long long m = 0;
+#pragma unroll
+                    for (int b = 0; b < NSB - 1; ++b) if (b == k) m = m_ray[b];
+                    pos = s_q[3 + k][wv] + (uint32_t)__popcll(m & lt);
+                } else {
+                    pos = pos_last++;
+                }
+                const int b = k < NSB - 1 ? k : NSB - 1;
+                const size_t qi = (size_t)b * pl.cap + pos;
+                float4 a = park[2 * k], bb = park[2 * k + 1];
+                bb.w = u2f(slot * (uint32_t)pl.nshadow + (uint32_t)k);
+                pl.q_sray_a[qi] = a; pl.q_sray_b[qi] = bb;
             }
         }
     }
@@ -906,11 +937,12 @@ static void launch_render_extend(ptmi_ctx *ctx, const Pool &pl, const DevScene &
     else launch_render_extend_t<64>(ctx, pl, sc, ra, qray, n, s);
 }
 template <int STACK>
-static void launch_render_connect_t(ptmi_ctx *ctx, const Pool &pl, uint32_t n, hipStream_t s) {
-    hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n,
-                       ctx->d_counters);
+static void launch_render_connect_t(ptmi_ctx *ctx, const Pool &pl, const ShadowCounts &n, hipStream_t s) {
+    unsigned blocks = 0;
+    for (int b = 0; b < NSB; ++b) blocks += (n.n[b] + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(blocks), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n, ctx->d_counters);
 }
-static void launch_render_connect(ptmi_ctx *ctx, const Pool &pl, uint32_t n, hipStream_t s) {
+static void launch_render_connect(ptmi_ctx *ctx, const Pool &pl, const ShadowCounts &n, hipStream_t s) {
     const int dep = ctx->max_depth;
     if (dep <= 16) launch_render_connect_t<16>(ctx, pl, n, s);
     else if (dep <= 24) launch_render_connect_t<24>(ctx, pl, n, s);
@@ -929,7 +961,8 @@ struct Lane {
     hipStream_t st = nullptr;
     uint64_t next_sample = 0, end_sample = 0;
     int cur = 0;
-    uint32_t n_ext = 0, n_shp = 0, n_srays = 0;
+    uint32_t n_ext = 0, n_shp = 0;
+    ShadowCounts n_srays{};
     bool inflight = false;
     hipEvent_t ev_trav = nullptr;        // recorded after this lane's extend + connect
     bool ev_recorded = false;
@@ -944,7 +977,9 @@ static int lane_enqueue(ptmi_ctx *ctx, Lane &L, Lane *other, const DevScene &sc,
     PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, qc_bytes, L.st));
     if (other && other->ev_recorded) PTMI_HIP(ctx, hipStreamWaitEvent(L.st, other->ev_trav, 0));
     if (L.n_ext) launch_render_extend(ctx, pl, sc, ra, pl.q_ext_ray[cur], L.n_ext, L.st);
-    if (L.n_srays) launch_render_connect(ctx, pl, L.n_srays, L.st);
+    uint32_t nsr = 0;
+    for (int b = 0; b < NSB; ++b) nsr += L.n_srays.n[b];
+    if (nsr) launch_render_connect(ctx, pl, L.n_srays, L.st);
     if (other) { PTMI_HIP(ctx, hipEventRecord(L.ev_trav, L.st)); L.ev_recorded = true; }
     const uint32_t nshade = L.n_ext + L.n_shp;
     hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), 0, L.st, pl, sc, ra, pl.q_ext[cur], L.n_ext,
@@ -965,9 +1000,13 @@ static int lane_finish(ptmi_ctx *ctx, Lane &L, const RenderArgs &ra) {
     const uint32_t n_free = (uint32_t)L.hc[QC_FREE * QC_STRIDE];
     uint32_t ne = (uint32_t)L.hc[(QC_EXT0 + nxt) * QC_STRIDE];
     L.n_shp = (uint32_t)L.hc[(QC_SHP0 + nxt) * QC_STRIDE];
-    L.n_srays = (uint32_t)L.hc[QC_SRAY * QC_STRIDE];
-    if (ne > pl.cap || L.n_shp > pl.cap || n_free > pl.cap || L.n_srays > pl.cap * (uint32_t)pl.nshadow)
-        return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: queue counter out of range");
+    bool bad = ne > pl.cap || L.n_shp > pl.cap || n_free > pl.cap;
+    for (int b = 0; b < NSB; ++b) {
+        L.n_srays.n[b] = (uint32_t)L.hc[(size_t)(QC_SRAY + b) * QC_STRIDE];
+        const uint64_t room = b < NSB - 1 ? (uint64_t)pl.cap : (uint64_t)pl.cap * (uint64_t)std::max(pl.nshadow - (NSB - 1), 0);
+        bad = bad || L.n_srays.n[b] > room;
+    }
+    if (bad) return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: queue counter out of range");
     if (n_free && L.next_sample < L.end_sample) {
         const uint32_t ng = (uint32_t)std::min<uint64_t>(n_free, L.end_sample - L.next_sample);
         hipLaunchKernelGGL(generate_kernel, dim3((ng + 255) / 256), dim3(256), 0, L.st, pl, ra, (const uint32_t *)pl.q_free, ng,
