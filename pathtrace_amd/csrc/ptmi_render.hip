@@ -262,7 +262,7 @@ __device__ __forceinline__ bool is_emissive(const PtMaterial &m) { return m.ke[0
 // States of the per-path machine inside one shade invocation.
 enum { ST_EXTENDED, ST_MATERIAL, ST_SHADOW_DONE, ST_GI_LOOP, ST_REFL_LOOP, ST_DIFFUSE_FINAL, ST_COMBINE, ST_RETURN };
 
-__global__ __launch_bounds__(256) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, const uint32_t *list_a,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, const uint32_t *list_a,
                                                     uint32_t na, const uint32_t *list_b, uint32_t nb,
                                                     uint32_t *q_ext_next, float4 *q_ray_next, uint32_t *q_shpath_next,
                                                     unsigned long long *qc_ext_next, unsigned long long *qc_shp_next,
@@ -874,6 +874,18 @@ static size_t carve(size_t &off, size_t bytes) {
     return o;
 }
 
+static int tracker_words(int bounces) {
+    // every TraceRay invocation can push one index and the sibling subtrees share the tracker, so its history is
+    // bounded by the number of invocations, 2^(bounces+1)-1 (capped at 64 entries, like the oracle)
+    int ntrk = bounces + 1 >= 6 ? 64 : (1 << (bounces + 1)) + 1;
+    return (ntrk + 3) / 4 * 4;
+}
+// device bytes one path of the pool takes (records + its share of every queue)
+static uint64_t pool_bytes_per_path(int bounces, int nlights) {
+    const uint64_t nframes = (uint64_t)bounces + 1, nshadow = (uint64_t)nlights + 2;
+    return 64 + 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 + 32 + 32) * nshadow + 4 * 5 + 32 * 2;
+}
+
 static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     RenderState *rs = ctx->render;
     if (rs->pool_mem && rs->pool_cap == cap && rs->pool_bounces == bounces && rs->pool_nlights == (int)rs->nlights &&
@@ -881,10 +893,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
         return PTMI_OK;
     if (rs->pool_mem) { (void)hipFree(rs->pool_mem); rs->pool_mem = nullptr; }
     const int nframes = bounces + 1, nshadow = (int)rs->nlights + 2;
-    // every TraceRay invocation can push one index and the sibling subtrees share the tracker, so its history is
-    // bounded by the number of invocations, 2^(bounces+1)-1 (capped at 64 entries, like the oracle)
-    int ntrk = bounces + 1 >= 6 ? 64 : (1 << (bounces + 1)) + 1;
-    ntrk = (ntrk + 3) / 4 * 4;
+    const int ntrk = tracker_words(bounces);
     const size_t c = cap;
     struct Off { size_t hdr, fr, trk, sh, park, qe0, qe1, qs0, qs1, ra, rb, qr0, qr1, free_, cnt; } of[2];
     size_t off = 0;
@@ -1043,7 +1052,13 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     const uint64_t max_total = npix * spp_chunk;
     // two lanes of 2^20 paths when there is enough work to keep both busy, else one
     const int lanes = (ctx->render_lanes >= 2 && max_total >= (1ull << 18)) ? 2 : 1;
-    uint32_t cap = (uint32_t)std::min<uint64_t>((max_total + lanes - 1) / lanes, (1u << 21) / (uint32_t)lanes);
+    // Every wavefront iteration costs ~0.3 ms that does not depend on the number of paths (the tails of three kernels
+    // that wait for their longest rays, one host round trip), so the pool is as large as the work and the memory
+    // budget allow: 2 M paths reach 640 Msamples/s on C3, 16 M reach 760 (profiles/r01c/README.md).
+    const uint64_t path_bytes = pool_bytes_per_path(bounces, (int)rs->nlights);
+    const uint64_t by_budget = std::max<uint64_t>(1u << 16, ctx->pool_bytes_max / path_bytes);
+    uint32_t cap = (uint32_t)std::min<uint64_t>({(max_total + lanes - 1) / lanes, (uint64_t)ctx->pool_paths / (uint64_t)lanes,
+                                                 by_budget / (uint64_t)lanes});
     cap = (cap + 255) / 256 * 256;
     int rc = ensure_pool(ctx, cap, bounces, lanes);
     if (rc) return rc;
