@@ -60,8 +60,11 @@ static void run(const char *name, float4 *table, uint32_t nrec, uint32_t n, floa
     fflush(stdout);
 }
 
-int main() {
-    const uint32_t nrec = 1u << 21, n = 1u << 21;         // 2 M records, one access per record slot (with collisions)
+int main(int argc, char **argv) {
+    // default 2 M records = 256 MB (fits the 256 MB Infinity Cache); pass 24 for 16 M records = 2 GB (HBM)
+    const int lg = argc > 1 ? atoi(argv[1]) : 21;
+    const uint32_t nrec = 1u << lg, n = 1u << lg;         // one access per record slot (with collisions)
+    printf("%u records of 128 B\n", nrec);
     float *out; CK(hipMalloc(&out, 4));
     float4 *table; CK(hipMalloc(&table, (size_t)nrec * 128));
     CK(hipMemset(table, 0, (size_t)nrec * 128));
