@@ -50,9 +50,17 @@ enum { HS_MISS = 0, HS_HIT = 1, HS_HORIZON = 2 };
 enum { NSB = 8 };
 enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHP0 = 2, QC_SHP1 = 3, QC_FREE = 4, QC_SRAY = 5, QC_COUNT = QC_SRAY + NSB, QC_STRIDE = 16 };
 struct ShadowCounts { uint32_t n[NSB]; };
-// path header, 16 words = 64 bytes per slot
-enum { H_SID = 0, H_KEY = 1, H_CTR = 2, H_DEPTH = 3, H_TRKLEN = 4, H_HSTATUS = 5, H_HPRIM = 6, H_HT = 7,
-       H_VT0 = 8, H_VT1 = 9, H_RO = 10, H_RD = 13, HDRW = 16 };
+// Path header, 32 words = one 128-byte line per slot (8 x float4):
+//   q0  sample id, RNG key, RNG counter, packed (depth | tracker length << 8 | HP_PENDING)
+//   q1  tracker entry 0, hit status, hit primitive, hit t            (words 1-3 are written by extend)
+//   q2  V_t at the start of the geodesic, V_t now, ray origin x y    q3  origin z, direction
+//   q4  arguments of the pending TraceRay call: bounces, bounceIndex, flags, energy     q5  lastSurfaceNormal
+//   q6, q7  tracker entries 1-8 (deeper histories continue in Pool::trk)
+// HP_PENDING: the top of the recursion stack is a TraceRay call that has not looked at its hit yet.  Such a
+// frame has no contents beyond its arguments, so it lives in the header and frame memory is only touched when a
+// frame is parked under a child or waits for its shadow rays; a fresh sample is a pending call at depth 0.
+enum { HQ = 8, HW_TRK1 = 24, HDR_TRK = 8 };
+constexpr uint32_t HP_PENDING = 0x80000000u;
 
 // self-check failures reported through counters[CNT_ERROR] (a corrupted path is dropped, never dereferenced)
 enum { ERR_SLOT = 1, ERR_DEPTH = 2, ERR_PRIM = 4, ERR_MAT = 8, ERR_PHASE = 16 };
@@ -79,7 +87,7 @@ struct RenderArgs {
 struct Pool {
     uint32_t cap;
     int nframes, ntrk, nshadow;          // bounces+1, tracker history capacity (multiple of 4), nlights+2
-    float4 *hdr;                         // [cap][4]            header (H_*)
+    float4 *hdr;                         // [cap][HQ]           header
     float4 *fr;                          // [cap][nframes][8]   frames (F_*)
     float *trk;                          // [cap][ntrk]         RefractiveIndexTracker.indices
     float4 *sh;                          // [cap][nshadow]      (contribution.xyz, occluded as u32 bits)
@@ -140,46 +148,27 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, c
         gen_o = pos; gen_d = d;
         g_sid = sid; g_key = rng.key; g_ctr = rng.ctr;
     }
-    // The records are written cooperatively: 4 neighbouring lanes store one path's 64-byte header, 8 lanes one
-    // 128-byte frame, so a store instruction carries whole lines (scattered 128-byte records: 5.3 TB/s against
-    // 3.2 TB/s when every lane writes its own record 16 bytes at a time -- tools/ubench_scatter.hip).  Whole lines
-    // also spare the read-modify-write a partial write of an uncached line costs.
+    // A fresh sample is a header and nothing else (see HP_PENDING).  8 neighbouring lanes store one path's 128-byte
+    // header, so a store instruction carries whole lines (scattered 128-byte records: 5.3 TB/s against 3.2 TB/s
+    // when every lane writes its own record 16 bytes at a time -- tools/ubench_scatter.hip).
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t dead = 0xFFFFFFFFu;
     const uint32_t my = live ? slot : dead;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {                                      // headers: 16 paths per instruction
-        const int src = j * 16 + (int)(lane >> 2);
-        const uint32_t q = lane & 3u;
+    for (int j = 0; j < 8; ++j) {                                      // 8 lanes per header, 8 paths per instruction
+        const int src = j * 8 + (int)(lane >> 3);
+        const uint32_t q = lane & 7u;
         const uint32_t ps = __shfl(my, src);
         const uint32_t a0 = __shfl(g_sid, src), a1 = __shfl(g_key, src), a2 = __shfl(g_ctr, src);
         const float dx = __shfl(gen_d.x, src), dy = __shfl(gen_d.y, src), dz = __shfl(gen_d.z, src);
         const float ox = __shfl(gen_o.x, src), oy = __shfl(gen_o.y, src), oz = __shfl(gen_o.z, src);
-        float4 v;
-        if (q == 0) v = make_float4(u2f(a0), u2f(a1), u2f(a2), i2f(0));
-        else if (q == 1) v = make_float4(u2f(1u), i2f(HS_MISS), i2f(-1), 0.0f);
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (q == 0) v = make_float4(u2f(a0), u2f(a1), u2f(a2), u2f(HP_PENDING | (1u << 8)));   // depth 0, tracker {1.0}
+        else if (q == 1) v = make_float4(1.0f, i2f(HS_MISS), i2f(-1), 0.0f);
         else if (q == 2) v = make_float4(1.0f, 1.0f, ox, oy);
-        else v = make_float4(oz, dx, dy, dz);
-        if (ps != dead) pl.hdr[(size_t)ps * 4 + q] = v;
-    }
-    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {                                      // frame 0: 8 paths per instruction
-        const int src = j * 8 + (int)(lane >> 3);
-        const uint32_t q = lane & 7u;
-        const uint32_t ps = __shfl(my, src);
-        float4 v = z;
-        if (q == 0) v = make_float4(i2f(ra.p.bounces), i2f(0), u2f(0u), 1.0f);
-        if (q == 7) v = make_float4(0.0f, u2f((uint32_t)PH_EXTEND), 0.0f, 0.0f);     // word F_PHASE = 29
-        if (ps != dead) pl.fr[(size_t)ps * pl.nframes * 8 + q] = v;
-    }
-    {                                                                  // tracker: index 0 = 1.0, one 32-byte sector
-        const uint32_t nq = pl.ntrk >= 8 ? 2u : 1u;
-        for (uint32_t k = lane; k < 64u * nq; k += 64u) {
-            const uint32_t ps = __shfl(my, (int)(k / nq));
-            const uint32_t q = k % nq;
-            if (ps != dead) ((float4 *)(pl.trk + (size_t)ps * pl.ntrk))[q] = q == 0 ? make_float4(1.0f, 0.0f, 0.0f, 0.0f) : z;
-        }
+        else if (q == 3) v = make_float4(oz, dx, dy, dz);
+        else if (q == 4) v = make_float4(i2f(ra.p.bounces), i2f(0), u2f(0u), 1.0f);             // main.go:875
+        if (ps != dead) pl.hdr[(size_t)ps * HQ + q] = v;
     }
     // TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0; shade handles that case
     if (live) {
@@ -206,7 +195,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
         const float4 qa = qray[2 * (size_t)i], qb = qray[2 * (size_t)i + 1];
         uint32_t slot = f2u(qa.w);
         if (slot >= pl.cap) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT); slot = 0; }
-        float4 *hd = pl.hdr + (size_t)slot * 4;
+        float4 *hd = pl.hdr + (size_t)slot * HQ;
         V3 o = mk(qa.x, qa.y, qa.z);
         V3 d = mk(qb.x, qb.y, qb.z);
         RayState st = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -314,17 +303,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         slot = i < na ? list_a[i] : list_b[i - na];
         uint32_t err = 0;
         if (slot >= pl.cap) { err = ERR_SLOT; slot = 0; }
-        float4 *hd = pl.hdr + (size_t)slot * 4;
-        const float4 h0 = hd[0], h1 = hd[1], h2 = hd[2], h3 = hd[3];
+        float4 *hd = pl.hdr + (size_t)slot * HQ;
+        const float4 h0 = hd[0], h1 = hd[1], h2 = hd[2], h3 = hd[3], h4 = hd[4], h5 = hd[5];
         const uint32_t sid = f2u(h0.x);
         Rng rng; rng.key = f2u(h0.y); rng.ctr = f2u(h0.z);
-        int depth = f2i(h0.w);
-        if (depth < 0 || depth >= pl.nframes) { err |= ERR_DEPTH; depth = 0; }
-        uint32_t trk_len = f2u(h1.x);
+        const uint32_t packed = f2u(h0.w);
+        int depth = (int)(packed & 0xFFu);
+        if (depth >= pl.nframes) { err |= ERR_DEPTH; depth = 0; }
+        uint32_t trk_len = (packed >> 8) & 0xFFu;
+        if ((int)trk_len > pl.ntrk) { err |= ERR_DEPTH; trk_len = 0; }
+        const bool pending = (packed & HP_PENDING) != 0;
+        if (pending != (i < na)) err |= ERR_PHASE;                          // the extend list holds exactly the pending calls
+        float trk0 = h1.x;
         const int hs = f2i(h1.y), hprim = f2i(h1.z);
         const float ht = h1.w, vt0 = h2.x, vt1 = h2.y;
         V3 cur_o = mk(h2.z, h2.w, h3.x), cur_d = mk(h3.y, h3.z, h3.w);      // the path's current ray
+        float *hw = (float *)hd;
         float *trk = pl.trk + (size_t)slot * pl.ntrk;
+        // arguments of a child call pushed in this invocation (they go into the header when the path parks)
+        int arg_bounces = 0, arg_bindex = 0; uint32_t arg_flags = 0; float arg_energy = 0.0f; V3 arg_ln = mk(0, 0, 0);
         float4 *frames = pl.fr + (size_t)slot * pl.nframes * 8;
         float4 *shp = pl.sh + (size_t)slot * pl.nshadow;
         float4 *park = pl.park + (size_t)slot * pl.nshadow * 2;
@@ -349,8 +346,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #define FU(field) f2u(FW(field))
 #define FI_SET(field, v) (FW(field) = i2f(v))
 #define FU_SET(field, v) (FW(field) = u2f(v))
-        auto trk_current = [&]() -> float { return trk_len == 0 ? 1.0f : trk[trk_len - 1]; };
-        auto trk_previous = [&]() -> float { return trk_len < 2 ? 1.0f : trk[trk_len - 2]; };
+        // RefractiveIndexTracker.indices: entry 0 in a register (header), 1-8 in the header line, the rest in Pool::trk
+        auto trk_get = [&](uint32_t e) -> float { return e == 0 ? trk0 : e <= (uint32_t)HDR_TRK ? hw[HW_TRK1 + e - 1] : trk[e - 1 - HDR_TRK]; };
+        auto trk_set = [&](uint32_t e, float v) {
+            if (e == 0) trk0 = v; else if (e <= (uint32_t)HDR_TRK) hw[HW_TRK1 + e - 1] = v; else trk[e - 1 - HDR_TRK] = v;
+        };
+        auto trk_current = [&]() -> float { return trk_len == 0 ? 1.0f : trk_get(trk_len - 1); };
+        auto trk_previous = [&]() -> float { return trk_len < 2 ? 1.0f : trk_get(trk_len - 2); };
 
         // (re)derive the hit of the top frame from what the frame stores
         auto load_hit = [&](Hit &h) {
@@ -370,13 +372,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             diffuse_surface(sc.mats[h.mat], sc.uvs, sc.tex, sc.ntex, sc.tex_pixels, (uint32_t)h.prim, h.P, h.A, h.B, h.C,
                             h.albedo, h.dnormal);
         };
-        // park the top frame, push a child TraceRay invocation above it and request its extend
+        // park the top frame and make a child TraceRay invocation the pending call; the caller requests its extend
         auto push_child = [&](int dep, int bounces, int bindex, V3 lastN, bool specular, float energy, V3 o, V3 d) {
             store_frame(dep);
-            float4 *f = frames + (size_t)(dep + 1) * 8;
-            f[0] = make_float4(i2f(bounces), i2f(bindex), u2f(specular ? (uint32_t)FL_SPECULAR : 0u), energy);
-            f[1] = make_float4(lastN.x, lastN.y, lastN.z, 0.0f);
-            ((uint32_t *)f)[F_PHASE] = PH_EXTEND;
+            arg_bounces = bounces; arg_bindex = bindex; arg_flags = specular ? (uint32_t)FL_SPECULAR : 0u;
+            arg_energy = energy; arg_ln = lastN;
             cur_o = o; cur_d = d;
         };
 
@@ -384,12 +384,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         V3 ret = mk(0, 0, 0);
         Hit h;
         bool have_hit = false;
-        load_frame(depth);
-        // entry: what was the top frame waiting for?
-        {
-            uint32_t ph = FU(F_PHASE);
-            if (ph == PH_EXTEND) state = ST_EXTENDED;
-            else if (ph == PH_SHADOW_WAIT) { load_hit(h); have_hit = true; state = ST_SHADOW_DONE; }
+        // entry: a pending call starts from its arguments, a parked frame comes back with its shadow answers
+        if (pending) {
+            FW(F_BOUNCES) = h4.x; FW(F_BINDEX) = h4.y; FW(F_FLAGS) = h4.z; FW(F_ENERGY) = h4.w;
+            FW(F_LN) = h5.x; FW(F_LN + 1) = h5.y; FW(F_LN + 2) = h5.z;
+            FU_SET(F_PHASE, PH_EXTEND);
+            state = ST_EXTENDED;
+        } else {
+            load_frame(depth);
+            if (FU(F_PHASE) == PH_SHADOW_WAIT) { load_hit(h); have_hit = true; state = ST_SHADOW_DONE; }
             else { err |= ERR_PHASE; state = ST_RETURN; depth = 0; }
         }
         for (;;) {
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     const float energy = FW(F_ENERGY);
                     int cbi = bindex + 1;
                     if (!tir) {
-                        if (goingOut) { if (trk_len > 0) trk_len--; } else if ((int)trk_len < pl.ntrk) { trk[trk_len] = ri; trk_len++; }
+                        if (goingOut) { if (trk_len > 0) trk_len--; } else if ((int)trk_len < pl.ntrk) { trk_set(trk_len, ri); trk_len++; }
                         cbi = bindex;
                     }
                     const float ce = energy * (float)0.95;
@@ -663,11 +666,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             want_extend = want_shadow = false; n_sray = 0; finished = true;
         }
         if (!finished) {
-            hd[0] = make_float4(h0.x, h0.y, u2f(rng.ctr), i2f(depth));
-            hd[1] = make_float4(u2f(trk_len), h1.y, h1.z, h1.w);
+            hd[0] = make_float4(h0.x, h0.y, u2f(rng.ctr), u2f((uint32_t)depth | trk_len << 8 | (want_extend ? HP_PENDING : 0u)));
+            hd[1] = make_float4(trk0, h1.y, h1.z, h1.w);
             if (want_extend) {
                 hd[2] = make_float4(h2.x, h2.y, cur_o.x, cur_o.y);
                 hd[3] = make_float4(cur_o.z, cur_d.x, cur_d.y, cur_d.z);
+                hd[4] = make_float4(i2f(arg_bounces), i2f(arg_bindex), u2f(arg_flags), arg_energy);
+                hd[5] = make_float4(arg_ln.x, arg_ln.y, arg_ln.z, 0.0f);
                 out_o = cur_o; out_d = cur_d;
             }
         }
@@ -916,7 +921,7 @@ static int tracker_words(int bounces) {
 // device bytes one path of the pool takes (records + its share of every queue)
 static uint64_t pool_bytes_per_path(int bounces, int nlights) {
     const uint64_t nframes = (uint64_t)bounces + 1, nshadow = (uint64_t)nlights + 2;
-    return 64 + 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 + 32 + 32) * nshadow + 4 * 5 + 32 * 2;
+    return 128 + 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 + 32 + 32) * nshadow + 4 * 5 + 32 * 2;
 }
 
 static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
@@ -932,7 +937,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     size_t off = 0;
     for (int l = 0; l < lanes; ++l) {
         Off &o = of[l];
-        o.hdr = carve(off, 64 * c); o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
+        o.hdr = carve(off, 128 * c); o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
         o.sh = carve(off, 16 * c * nshadow); o.park = carve(off, 32 * c * nshadow);
         o.qe0 = carve(off, 4 * c); o.qe1 = carve(off, 4 * c); o.qs0 = carve(off, 4 * c); o.qs1 = carve(off, 4 * c);
         o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow);
