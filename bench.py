@@ -120,7 +120,7 @@ def cpu_baseline(wl, args):
 def render_leg(args, rank, world, dist, dev, torch):
     """Secondary figure (not `value`): samples/s of the full wavefront integrator on BASELINE.json configs[2]
     (C3: glass + emissive + gradient sky, 1920x1080, 256 spp, bounces 2).  With N > 1 the frame is sharded by
-    64x64 tiles over the ranks and reduced onto rank 0 with RCCL (strong scaling)."""
+    blocks of 8 rows over the ranks and reduced onto rank 0 with RCCL (strong scaling)."""
     from pathtrace_amd import scenes, sharded
     from pathtrace_amd.render import Renderer, make_params
     sc = scenes.bunny_scene(blob_level=6, glass=True, emissive=True)
@@ -130,16 +130,12 @@ def render_leg(args, rank, world, dist, dev, torch):
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     cnt = torch.zeros((H, W), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    rr = sharded.make_device_render_rect(r, p, sc.camera, stream)
-    # tiles of one rank are merged into row strips of full-width rows where possible: use row-interleaved strips
+    rows = sharded.make_device_render_rows(r, p, sc.camera, stream)
+
     def run(spp_):
-        acc.zero_(); cnt.zero_()
-        rects = sharded.my_tiles(W, H, world, rank, tile=64) if world > 1 else [(0, 0, W, H)]
-        for rect in sharded.merge_rects(rects):
-            rr(acc, cnt, rect, 0, spp_)
-        if dist is not None:
-            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
-            dist.reduce(cnt, dst=0, op=dist.ReduceOp.SUM)
+        # every rank renders its row-interleaved share of the frame in one call, then one reduce onto rank 0
+        sharded.render_sharded(None, acc, cnt, W, H, spp_, rank=rank, world=world, dist=dist, dst=0, mode="rows",
+                               render_rows=rows, row_block=8)
     run(1)                                   # warm-up: pool allocation, RCCL channel set-up
     torch.cuda.synchronize()
     if dist is not None:
@@ -165,7 +161,7 @@ def render_leg(args, rank, world, dist, dev, torch):
             "config": {"workload": "C3: blob + glass spheres + emissive quad + mirror sphere, gradient sky + sun "
                                    "(BASELINE.json configs[2])", "width": W, "height": H, "spp": spp, "bounces": 2,
                        "triangles": int(sc.tris.shape[0]),
-                       "sharding": "single GPU" if world == 1 else f"64x64 tiles round-robin over {world} ranks + RCCL reduce"},
+                       "sharding": "single GPU" if world == 1 else f"blocks of 8 rows round-robin over {world} ranks, one render call per rank + RCCL reduce"},
             "closest_hit_Mqueries_per_s": round(q[1] / q[0] / 1e6, 1), "any_hit_Mqueries_per_s": round(q[2] / q[0] / 1e6, 1),
             "diffuse_events_M_per_s": round(q[3] / q[0] / 1e6, 1), "frame_complete": complete}
 

@@ -226,6 +226,14 @@ int ptmi_render(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, i
 int ptmi_render_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t x0, int32_t y0, int32_t w,
                     int32_t h, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb, uint32_t *counts,
                     void *stream);
+/* One GPU's share of a frame in ONE call: the rows y with (y / row_block) % nshards == shard, full width, added
+ * into FULL-FRAME device buffers accum_rgb[height*width*3] / counts[height*width] (other rows untouched).  The
+ * reference deals 64x64 tiles to goroutines (main.go:454-491, :935-937); a GPU wants its whole share at once --
+ * the wavefront loop costs ~0.3 ms per iteration whatever the number of paths in it -- so the shard is an
+ * interleave of row blocks, and a sum of the shards' buffers (RCCL reduce) is the frame. */
+int ptmi_render_rows_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t row_block,
+                         int32_t shard, int32_t nshards, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
+                         uint32_t *counts, void *stream);
 /* Per-sample radiance without accumulation: out[(pixel*spp_count + s)*3], host buffer. */
 int ptmi_render_samples(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t x0, int32_t y0,
                         int32_t w, int32_t h, uint32_t spp_begin, uint32_t spp_count, float *out_rgb);

@@ -79,6 +79,9 @@ struct RenderArgs {
     PtCamera cam;
     PtParams p;
     int x0, y0, w, h;
+    // row m of the region is image row y0 + (m / row_block) * row_period + m % row_block: a plain rectangle has
+    // row_block = row_period = h, a row-interleaved shard (ptmi_render_rows_dev) takes every nshards-th block of rows
+    int row_block, row_period;
     uint32_t spp_begin, spp_chunk;       // this batch covers samples [spp_begin, spp_begin+spp_chunk) of every pixel
     uint64_t total;                      // w*h*spp_chunk
 };
@@ -137,7 +140,8 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, c
         slot = slots ? slots[i] : i;
         const uint32_t sid = (uint32_t)first_sample + i;                   // total < 2^32/3 (render_core)
         uint32_t pix = sid / ra.spp_chunk, s = sid % ra.spp_chunk;
-        int X = ra.x0 + (int)(pix % (uint32_t)ra.w), Y = ra.y0 + (int)(pix / (uint32_t)ra.w);
+        const int m = (int)(pix / (uint32_t)ra.w);
+        int X = ra.x0 + (int)(pix % (uint32_t)ra.w), Y = ra.y0 + (m / ra.row_block) * ra.row_period + m % ra.row_block;
         Rng rng = rng_init(ra.p.seed, (uint32_t)(Y * ra.p.width + X), ra.spp_begin + s);
         float rx = ((float)X + rng_f32(rng)) / (float)ra.p.width;
         float ry = ((float)Y + rng_f32(rng)) / (float)ra.p.height;
@@ -756,15 +760,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 // ------------------------------------------------------------------------------------------ accumulate
 // Pixel.AddSample's running sums (renderer.go:29, 59-61): R += c.X ... in sample order.
+// frame_width = 0: accum / counts are the region's own [h][w] buffers; otherwise they are full frames of that
+// width and pixel (x, y) of the image is element y * frame_width + x.
 __global__ __launch_bounds__(256) void accumulate_kernel(const float *out, uint32_t npix, uint32_t spp, float *accum,
-                                                         uint32_t *counts) {
+                                                         uint32_t *counts, RenderArgs ra, int frame_width) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
-    float r = accum[3 * (size_t)p], g = accum[3 * (size_t)p + 1], b = accum[3 * (size_t)p + 2];
+    size_t q = p;
+    if (frame_width > 0) {
+        const int m = (int)(p / (uint32_t)ra.w), x = ra.x0 + (int)(p % (uint32_t)ra.w);
+        const int y = ra.y0 + (m / ra.row_block) * ra.row_period + m % ra.row_block;
+        q = (size_t)y * (size_t)frame_width + (size_t)x;
+    }
+    float r = accum[3 * q], g = accum[3 * q + 1], b = accum[3 * q + 2];
     const float *o = out + 3 * (size_t)p * spp;
     for (uint32_t s = 0; s < spp; ++s) { r += o[3 * s]; g += o[3 * s + 1]; b += o[3 * s + 2]; }
-    accum[3 * (size_t)p] = r; accum[3 * (size_t)p + 1] = g; accum[3 * (size_t)p + 2] = b;
-    counts[p] += spp;
+    accum[3 * q] = r; accum[3 * q + 1] = g; accum[3 * q + 2] = b;
+    counts[q] += spp;
 }
 
 }  // namespace
@@ -1069,14 +1081,21 @@ static int lane_finish(ptmi_ctx *ctx, Lane &L, const RenderArgs &ra) {
 
 // Renders samples [spp_begin, spp_begin+spp_count) of the rectangle into d_out chunks and accumulates them
 // into d_accum / d_counts (device pointers); or, when out_samples_host != nullptr, copies raw samples out.
+// A row-interleaved shard is given by row_block > 0 (then y0 = first row of the shard, h = its number of rows,
+// row_period = row_block * shards, and d_accum / d_counts are full frames).
 static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, int x0, int y0, int w, int h,
                        uint32_t spp_begin, uint32_t spp_count, float *d_accum, uint32_t *d_counts, float *out_samples_host,
-                       hipStream_t s) {
+                       hipStream_t s, int row_block = 0, int row_period = 0) {
     RenderState *rs = ctx->render;
     if (!rs || !rs->have_scene) return set_err(ctx, PTMI_ERR_NO_SCENE, "ptmi_render: no scene uploaded");
     if (!cam || !prm) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: null camera / params");
-    if (w <= 0 || h <= 0 || prm->width <= 0 || prm->height <= 0 || x0 < 0 || y0 < 0 || x0 + w > prm->width || y0 + h > prm->height)
+    const bool rows_mode = row_block > 0;
+    if (w <= 0 || h <= 0 || prm->width <= 0 || prm->height <= 0 || x0 < 0 || y0 < 0 || x0 + w > prm->width ||
+        (!rows_mode && y0 + h > prm->height))
         return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: rectangle outside the image");
+    if (!rows_mode) { row_block = h; row_period = h; }
+    else if (y0 + ((h - 1) / row_block) * row_period + (h - 1) % row_block >= prm->height)
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: row shard outside the image");
     if (prm->bounces > 30 || prm->scatter_rays < 1 || prm->max_steps < 0)
         return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: need bounces <= 30, scatter_rays >= 1, max_steps >= 0");
     if (spp_count == 0) return PTMI_OK;
@@ -1124,6 +1143,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         const uint32_t chunk = std::min(spp_chunk, spp_count - done);
         RenderArgs ra{};
         ra.cam = *cam; ra.p = *prm; ra.x0 = x0; ra.y0 = y0; ra.w = w; ra.h = h;
+        ra.row_block = row_block; ra.row_period = row_period;
         ra.spp_begin = spp_begin + done; ra.spp_chunk = chunk; ra.total = npix * chunk;
 
         // lane 1's stream joins the caller's stream here and hands back at the end of the chunk
@@ -1182,7 +1202,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             PTMI_HIP(ctx, hipStreamSynchronize(s));
         } else {
             hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rs->d_out,
-                               (uint32_t)npix, chunk, d_accum, d_counts);
+                               (uint32_t)npix, chunk, d_accum, d_counts, ra, rows_mode ? prm->width : 0);
             PTMI_HIP(ctx, hipGetLastError());
         }
     }
@@ -1196,6 +1216,27 @@ extern "C" int ptmi_render_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtPa
     if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_render_dev: no BVH");
     if (!accum_rgb || !counts) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_dev: null buffer");
     int rc = render_core(ctx, camera, params, x0, y0, w, h, spp_begin, spp_count, accum_rgb, counts, nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+    PTMI_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_render_rows_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t row_block,
+                                    int32_t shard, int32_t nshards, uint32_t spp_begin, uint32_t spp_count,
+                                    float *accum_rgb, uint32_t *counts, void *stream) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_render_rows_dev: ctx is null");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_render_rows_dev: no BVH");
+    if (!accum_rgb || !counts || !params) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_rows_dev: null argument");
+    if (row_block < 1 || nshards < 1 || shard < 0 || shard >= nshards)
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_rows_dev: need row_block >= 1 and 0 <= shard < nshards");
+    // rows of this shard: blocks shard, shard + nshards, ... of row_block rows each (the last block may be short)
+    int64_t rows = 0;
+    for (int64_t b = shard; b * row_block < params->height; b += nshards)
+        rows += std::min<int64_t>(row_block, params->height - b * row_block);
+    if (rows == 0) return PTMI_OK;
+    if ((int64_t)row_block * nshards > 0x7FFFFFFF) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_rows_dev: row_block too large");
+    int rc = render_core(ctx, camera, params, 0, shard * row_block, params->width, (int)rows, spp_begin, spp_count, accum_rgb,
+                         counts, nullptr, (hipStream_t)stream, row_block, row_block * nshards);
     if (rc) return rc;
     PTMI_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     return PTMI_OK;

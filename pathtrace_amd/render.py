@@ -121,6 +121,17 @@ class Renderer:
         check(self._lib.ptmi_render_dev(self.ctx.handle, C.byref(cam), C.byref(params), x0, y0, w, h, spp_begin, spp,
                                         accum.data_ptr(), counts.data_ptr(), s), self.ctx.handle)
 
+    def render_rows_device(self, accum, counts, params: PtParams, camera, shard=0, nshards=1, row_block=8, spp=32,
+                           spp_begin=0, stream=None):
+        """One GPU's row-interleaved share of the frame in one call, added into FULL-FRAME torch CUDA tensors
+        (f32 [H,W,3], i32/u32 [H,W]): rows y with (y // row_block) % nshards == shard."""
+        cam = camera if isinstance(camera, PtCamera) else make_camera(camera)
+        assert tuple(accum.shape) == (params.height, params.width, 3) and accum.is_contiguous()
+        assert tuple(counts.shape) == (params.height, params.width) and counts.is_contiguous()
+        s = C.c_void_p(stream) if stream else None
+        check(self._lib.ptmi_render_rows_dev(self.ctx.handle, C.byref(cam), C.byref(params), row_block, shard, nshards,
+                                             spp_begin, spp, accum.data_ptr(), counts.data_ptr(), s), self.ctx.handle)
+
     def render_samples(self, params: PtParams, camera, rect=None, spp=1, spp_begin=0):
         """Per-sample radiance [h,w,spp,3] (no accumulation) -- for fine-grained parity checks."""
         cam = camera if isinstance(camera, PtCamera) else make_camera(camera)

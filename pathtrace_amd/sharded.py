@@ -1,8 +1,11 @@
 """Multi-GPU sharding of a frame: one process per GPU, BVH + scene replicated, RCCL reduce of the framebuffer.
 
-The reference already renders a frame as independent tiles, one goroutine per tile (main.go:454-491, :935-937);
-here tiles are dealt round-robin to ranks (`tile_id % world == rank`, small tiles for load balance) and every
-rank adds its tiles into a zero-initialised full-frame accumulator, which is then summed onto `dst` with one
+The reference already renders a frame as independent tiles, one goroutine per tile (main.go:454-491, :935-937).
+A GPU wants its whole share in ONE call (every wavefront iteration costs ~0.3 ms whatever the number of paths in
+it, so a 64x64 tile never fills the machine): `mode="rows"` deals blocks of `row_block` rows round-robin to ranks
+(`(y // row_block) % world == rank`, rendered by ptmi_render_rows_dev in one pass); `mode="tile"` keeps the
+reference's granularity (`tile_id % world == rank`, one call per merged tile strip).  Every
+rank adds its share into a zero-initialised full-frame accumulator, which is then summed onto `dst` with one
 `torch.distributed.reduce` (backend "nccl" = RCCL over xGMI; 4K frame = 99.5 MB + 33 MB of counts).  Regions are
 disjoint, so the reduced sums are bit-identical to a single-GPU render (x + 0 == x).  RNG streams are keyed by
 (pixel, sample), so the image does not depend on the number of ranks.  `mode="sample"` splits the sample range
@@ -26,6 +29,11 @@ def my_tiles(width, height, world, rank, tile=64):
     return [r for i, r in enumerate(tile_rects(width, height, tile)) if i % world == rank]
 
 
+def my_rows(height, world, rank, row_block=8):
+    """Rows of `rank` under the row-block interleave of ptmi_render_rows_dev."""
+    return [y for y in range(height) if (y // row_block) % world == rank]
+
+
 def sample_range(spp, world, rank):
     """Contiguous sample sub-range of `rank` (first ranks take the remainder)."""
     base, rem = divmod(spp, world)
@@ -45,7 +53,7 @@ def merge_rects(rects):
 
 
 def render_sharded(render_rect, accum, counts, width, height, spp, rank=0, world=1, dist=None, dst=0, mode="tile",
-                   tile=64, group=None):
+                   tile=64, group=None, render_rows=None, row_block=8):
     """Render this rank's shard with `render_rect(rect, spp_begin, spp)` (which must ADD into the rows/cols of the
     full-frame tensors `accum` [H,W,3] / `counts` [H,W] it is given views of) and reduce onto `dst`.
 
@@ -56,6 +64,11 @@ def render_sharded(render_rect, accum, counts, width, height, spp, rank=0, world
     if mode == "tile":
         for (x0, y0, w, h) in my_tiles(width, height, world, rank, tile):
             render_rect(accum, counts, (x0, y0, w, h), 0, spp)
+    elif mode == "rows":
+        # render_rows(accum, counts, shard, nshards, row_block, spp_begin, spp_count): one call for the whole share
+        if render_rows is None:
+            raise ValueError("mode='rows' needs render_rows")
+        render_rows(accum, counts, rank, world, row_block, 0, spp)
     elif mode == "sample":
         b, n = sample_range(spp, world, rank)
         if n:
@@ -86,3 +99,11 @@ def make_device_render_rect(renderer, params, camera, stream=None):
         counts[y0:y0 + h, x0:x0 + w] += c
 
     return render_rect
+
+
+def make_device_render_rows(renderer, params, camera, stream=None):
+    """render_rows callable for the real backend (ptmi_render_rows_dev on full-frame CUDA tensors)."""
+    def render_rows(accum, counts, shard, nshards, row_block, spp_begin, spp_count):
+        renderer.render_rows_device(accum, counts, params, camera, shard, nshards, row_block, spp_count, spp_begin, stream)
+
+    return render_rows

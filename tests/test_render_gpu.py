@@ -9,7 +9,7 @@ equality is required for all but a small fraction of samples, and images are com
 import numpy as np
 import pytest
 
-from pathtrace_amd import scenes
+from pathtrace_amd import scenes, sharded
 from pathtrace_amd.render import Renderer, make_params
 import oracle_lib
 
@@ -117,6 +117,30 @@ def test_accumulation_counts_rects_and_counters(gpu_ctx):
     rgba = r.to_rgba(fb)
     want = oracle_lib.to_rgba(fb.accum, fb.counts)
     assert np.array_equal(rgba, want) and (rgba[:, 0, :3] == 0).all()
+
+
+def test_row_shards_sum_to_the_frame(gpu_ctx):
+    """ptmi_render_rows_dev: the shards of 1, 2 and 3 "ranks" cover the frame exactly once and their sum is the
+    single-call frame bit for bit (disjoint rows, per-pixel sample order unchanged)."""
+    import torch
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    W, H, spp = 72, 53, 3                                     # 53 rows: the last block of 8 is short
+    p = make_params(W, H, bounces=2, seed=5)
+    r = Renderer(sc, ctx=gpu_ctx)
+    dev = torch.device("cuda", 0)
+    ref = torch.zeros((H, W, 3), dtype=torch.float32, device=dev); refc = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    r.render_device(ref, refc, p, sc.camera, spp=spp)
+    for world in (1, 2, 3):
+        tot = torch.zeros_like(ref); totc = torch.zeros_like(refc)
+        for rank in range(world):
+            a = torch.zeros_like(ref); c = torch.zeros_like(refc)
+            r.render_rows_device(a, c, p, sc.camera, shard=rank, nshards=world, row_block=8, spp=spp)
+            mine = torch.zeros(H, dtype=torch.bool); mine[sharded.my_rows(H, world, rank, 8)] = True
+            assert (c.cpu()[mine] == spp).all() and (c.cpu()[~mine] == 0).all()
+            tot += a; totc += c
+        assert torch.equal(tot, ref) and torch.equal(totc, refc)
+    with pytest.raises(Exception):
+        r.render_rows_device(ref, refc, p, sc.camera, shard=2, nshards=2)
 
 
 def test_frame_loop_writes_frames(gpu_ctx, tmp_path):

@@ -24,6 +24,12 @@ def _fake_render_rect(accum, counts, rect, spp_begin, spp_count):
         counts[y0:y0 + h, x0:x0 + w] += 1
 
 
+def _fake_render_rows(accum, counts, shard, nshards, row_block, spp_begin, spp_count):
+    H, W = counts.shape
+    for y in sharded.my_rows(H, nshards, shard, row_block):
+        _fake_render_rect(accum, counts, (0, y, W, 1), spp_begin, spp_count)
+
+
 def _single(width, height, spp):
     a = torch.zeros((height, width, 3)); c = torch.zeros((height, width), dtype=torch.int32)
     _fake_render_rect(a, c, (0, 0, width, height), 0, spp)
@@ -42,6 +48,11 @@ def test_tile_plan_covers_frame_exactly_once():
         assert (cover == 1).all()
         if W * H >= 512 * 512:
             assert max(per_rank) <= 1.2 * min(per_rank)          # interleaving balances the load
+    for (H, world, block) in [(1080, 8, 8), (70, 3, 8), (5, 2, 8), (2160, 8, 16), (9, 4, 1)]:
+        rows = [sharded.my_rows(H, world, r, block) for r in range(world)]
+        assert sorted(y for rr in rows for y in rr) == list(range(H))
+        if H >= 1000:
+            assert max(map(len, rows)) - min(map(len, rows)) <= block
     assert [sharded.sample_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
     assert sum(n for _, n in (sharded.sample_range(7, 8, r) for r in range(8))) == 7
 
@@ -53,7 +64,7 @@ def _worker(rank, world, port, mode, q):
     W, H, spp = 96, 80, 5
     a = torch.zeros((H, W, 3)); c = torch.zeros((H, W), dtype=torch.int32)
     sharded.render_sharded(_fake_render_rect, a, c, W, H, spp, rank=rank, world=world, dist=dist, dst=0, mode=mode,
-                           tile=32)
+                           tile=32, render_rows=_fake_render_rows, row_block=8)
     if rank == 0:
         ra, rc = _single(W, H, spp)
         q.put((bool(torch.equal(a, ra)), bool(torch.equal(c, rc))))
@@ -61,7 +72,7 @@ def _worker(rank, world, port, mode, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["tile", "sample"])
+@pytest.mark.parametrize("mode", ["tile", "rows", "sample"])
 def test_reduce_matches_single_process(mode):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
