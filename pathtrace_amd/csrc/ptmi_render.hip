@@ -94,7 +94,6 @@ struct Pool {
     float4 *fr;                          // [cap][nframes][8]   frames (F_*)
     float *trk;                          // [cap][ntrk]         RefractiveIndexTracker.indices
     float4 *sh;                          // [cap][nshadow]      (contribution.xyz, occluded as u32 bits)
-    float4 *park;                        // [cap][nshadow][2]   a path's shadow rays until the queue reservation
     // queues
     uint32_t *q_ext[2];                  // extend queue (double buffered): slots ...
     float4 *q_ext_ray[2];                // ... and their rays, 2 x float4 per entry: (o.xyz, bits(slot)) / (d.xyz, -)
@@ -294,6 +293,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                     unsigned long long *qc_ext_next, unsigned long long *qc_shp_next,
                                                     unsigned long long *counters) {
     __shared__ float s_fw[FRW * 256];
+    // a path's shadow rays wait here, [ray k][word][thread] (7 words: origin, direction, range), until the workgroup
+    // has reserved their queue entries: 7 * nshadow * 256 floats of dynamic LDS
+    extern __shared__ float s_ray[];
     __shared__ uint32_t s_q[3 + NSB][4];       // [queue][wave]: counts, then bases (ext, shadow paths, free, NSB ray buckets)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < na + nb;
@@ -328,7 +330,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         int arg_bounces = 0, arg_bindex = 0; uint32_t arg_flags = 0; float arg_energy = 0.0f; V3 arg_ln = mk(0, 0, 0);
         float4 *frames = pl.fr + (size_t)slot * pl.nframes * 8;
         float4 *shp = pl.sh + (size_t)slot * pl.nshadow;
-        float4 *park = pl.park + (size_t)slot * pl.nshadow * 2;
 
         // The top frame lives in LDS, [word][thread] (conflict-free): it is read and written all over the state
         // machine below, and 32 more loop-carried registers per lane are what this kernel cannot afford.
@@ -496,9 +497,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 auto stage = [&](int k, V3 o, V3 d, float range, V3 contrib) {
                     need |= 1u << k;
                     shp[k] = make_float4(contrib.x, contrib.y, contrib.z, u2f(0u));
-                    // ray parked in the path's own slots; copied to the queue after the wave-wide reservation
-                    park[2 * k] = make_float4(o.x, o.y, o.z, range);
-                    park[2 * k + 1] = make_float4(d.x, d.y, d.z, 0.0f);
+                    float *sr = s_ray + (size_t)k * 7 * 256 + tid;
+                    sr[0] = o.x; sr[256] = o.y; sr[512] = o.z; sr[768] = d.x; sr[1024] = d.y; sr[1280] = d.z; sr[1536] = range;
                     n_sray++;
                 };
                 if (sc.sky.kind != PTMI_SKY_NONE) {                                                 // :531-542
@@ -735,7 +735,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (want_shadow) q_shpath_next[s_q[1][wv] + (uint32_t)__popcll(m_shp & lt)] = slot;
         if (finished) pl.q_free[s_q[2][wv] + (uint32_t)__popcll(m_fin & lt)] = slot;
         if (n_sray) {
-            const float4 *park = pl.park + (size_t)slot * pl.nshadow * 2;
             uint32_t pos_last = s_q[3 + NSB - 1][wv] + (incl - (uint32_t)__popc(last_bits));
             for (int k = 0; k < pl.nshadow; ++k) {
                 if (!(need_out >> k & 1u)) continue;
@@ -750,8 +749,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
                 const int b = k < NSB - 1 ? k : NSB - 1;
                 const size_t qi = (size_t)b * pl.cap + pos;
-                float4 a = park[2 * k], bb = park[2 * k + 1];
-                bb.w = u2f(slot * (uint32_t)pl.nshadow + (uint32_t)k);
+                const float *sr = s_ray + (size_t)k * 7 * 256 + threadIdx.x;
+                const float4 a = make_float4(sr[0], sr[256], sr[512], sr[1536]);
+                const float4 bb = make_float4(sr[768], sr[1024], sr[1280], u2f(slot * (uint32_t)pl.nshadow + (uint32_t)k));
                 pl.q_sray_a[qi] = a; pl.q_sray_b[qi] = bb;
             }
         }
@@ -838,7 +838,8 @@ extern "C" int ptmi_upload_scene(ptmi_ctx *ctx, const PtMaterial *materials, uin
     const uint64_t ntris = ctx->tri_idx.size() / 3;
     if (!materials || !nmaterials || (!tri_material && ntris) || (!corner_normals && ntris) || !sky || (!lights && nlights))
         return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: null array");
-    if (nlights > 29) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: at most 29 lights");
+    // shade stages a path's shadow rays (one per light + 2) in LDS: 7 KB per ray kind beside the 32 KB of frames
+    if (nlights > 16) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: at most 16 lights");
     for (uint64_t t = 0; t < ntris; ++t)
         if (tri_material[t] >= nmaterials) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: material index out of range");
     if (sky->kind < 0 || sky->kind > 3) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: bad sky kind");
@@ -933,7 +934,7 @@ static int tracker_words(int bounces) {
 // device bytes one path of the pool takes (records + its share of every queue)
 static uint64_t pool_bytes_per_path(int bounces, int nlights) {
     const uint64_t nframes = (uint64_t)bounces + 1, nshadow = (uint64_t)nlights + 2;
-    return 128 + 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 + 32 + 32) * nshadow + 4 * 5 + 32 * 2;
+    return 128 + 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 + 32) * nshadow + 4 * 5 + 32 * 2;
 }
 
 static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
@@ -945,12 +946,12 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     const int nframes = bounces + 1, nshadow = (int)rs->nlights + 2;
     const int ntrk = tracker_words(bounces);
     const size_t c = cap;
-    struct Off { size_t hdr, fr, trk, sh, park, qe0, qe1, qs0, qs1, ra, rb, qr0, qr1, free_, cnt; } of[2];
+    struct Off { size_t hdr, fr, trk, sh, qe0, qe1, qs0, qs1, ra, rb, qr0, qr1, free_, cnt; } of[2];
     size_t off = 0;
     for (int l = 0; l < lanes; ++l) {
         Off &o = of[l];
         o.hdr = carve(off, 128 * c); o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
-        o.sh = carve(off, 16 * c * nshadow); o.park = carve(off, 32 * c * nshadow);
+        o.sh = carve(off, 16 * c * nshadow);
         o.qe0 = carve(off, 4 * c); o.qe1 = carve(off, 4 * c); o.qs0 = carve(off, 4 * c); o.qs1 = carve(off, 4 * c);
         o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow);
         o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
@@ -964,7 +965,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
         Pool p{};
         p.cap = cap; p.nframes = nframes; p.nshadow = nshadow; p.ntrk = ntrk;
         p.hdr = (float4 *)(b + o.hdr); p.fr = (float4 *)(b + o.fr); p.trk = (float *)(b + o.trk);
-        p.sh = (float4 *)(b + o.sh); p.park = (float4 *)(b + o.park);
+        p.sh = (float4 *)(b + o.sh);
         p.q_ext[0] = (uint32_t *)(b + o.qe0); p.q_ext[1] = (uint32_t *)(b + o.qe1);
         p.q_ext_ray[0] = (float4 *)(b + o.qr0); p.q_ext_ray[1] = (float4 *)(b + o.qr1);
         p.q_shpath[0] = (uint32_t *)(b + o.qs0); p.q_shpath[1] = (uint32_t *)(b + o.qs1);
@@ -1041,7 +1042,10 @@ static int lane_enqueue(ptmi_ctx *ctx, Lane &L, Lane *other, const DevScene &sc,
     if (nsr) launch_render_connect(ctx, pl, L.n_srays, L.st);
     if (other) { PTMI_HIP(ctx, hipEventRecord(L.ev_trav, L.st)); L.ev_recorded = true; }
     const uint32_t nshade = L.n_ext + L.n_shp;
-    hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), 0, L.st, pl, sc, ra, pl.q_ext[cur], L.n_ext,
+    const size_t ray_lds = (size_t)7 * pl.nshadow * 256 * sizeof(float);
+    if (ray_lds > (28u << 10))      // beyond the default 64 KB of LDS per workgroup (gfx950 has 160 KB)
+        PTMI_HIP(ctx, hipFuncSetAttribute((const void *)shade_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds));
+    hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), ray_lds, L.st, pl, sc, ra, pl.q_ext[cur], L.n_ext,
                        pl.q_shpath[cur], L.n_shp, pl.q_ext[cur ^ 1], pl.q_ext_ray[cur ^ 1], pl.q_shpath[cur ^ 1],
                        qc(QC_EXT0 + (cur ^ 1)), qc(QC_SHP0 + (cur ^ 1)), ctx->d_counters);
     PTMI_HIP(ctx, hipGetLastError());
