@@ -293,8 +293,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                     unsigned long long *qc_ext_next, unsigned long long *qc_shp_next,
                                                     unsigned long long *counters) {
     __shared__ float s_fw[FRW * 256];
-    // a path's shadow rays wait here, [ray k][word][thread] (7 words: origin, direction, range), until the workgroup
-    // has reserved their queue entries: 7 * nshadow * 256 floats of dynamic LDS
+    // a path's shadow rays wait here, [word][thread], until the workgroup has reserved their queue entries: the two
+    // origins they start from (words 0-2: sky and light rays, 3-5: the emissive-triangle ray), then direction and
+    // range of ray k in words 6+4k .. 9+4k: (6 + 4 * nshadow) * 256 floats of dynamic LDS
     extern __shared__ float s_ray[];
     __shared__ uint32_t s_q[3 + NSB][4];       // [queue][wave]: counts, then bases (ext, shadow paths, free, NSB ray buckets)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -497,8 +498,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 auto stage = [&](int k, V3 o, V3 d, float range, V3 contrib) {
                     need |= 1u << k;
                     shp[k] = make_float4(contrib.x, contrib.y, contrib.z, u2f(0u));
-                    float *sr = s_ray + (size_t)k * 7 * 256 + tid;
-                    sr[0] = o.x; sr[256] = o.y; sr[512] = o.z; sr[768] = d.x; sr[1024] = d.y; sr[1280] = d.z; sr[1536] = range;
+                    float *so = s_ray + (k == pl.nshadow - 1 ? 3 : 0) * 256 + tid;     // rewritten per ray: same value
+                    so[0] = o.x; so[256] = o.y; so[512] = o.z;
+                    float *sr = s_ray + (size_t)(6 + 4 * k) * 256 + tid;
+                    sr[0] = d.x; sr[256] = d.y; sr[512] = d.z; sr[768] = range;
                     n_sray++;
                 };
                 if (sc.sky.kind != PTMI_SKY_NONE) {                                                 // :531-542
@@ -749,9 +752,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
                 const int b = k < NSB - 1 ? k : NSB - 1;
                 const size_t qi = (size_t)b * pl.cap + pos;
-                const float *sr = s_ray + (size_t)k * 7 * 256 + threadIdx.x;
-                const float4 a = make_float4(sr[0], sr[256], sr[512], sr[1536]);
-                const float4 bb = make_float4(sr[768], sr[1024], sr[1280], u2f(slot * (uint32_t)pl.nshadow + (uint32_t)k));
+                const float *so = s_ray + (k == pl.nshadow - 1 ? 3 : 0) * 256 + threadIdx.x;
+                const float *sr = s_ray + (size_t)(6 + 4 * k) * 256 + threadIdx.x;
+                const float4 a = make_float4(so[0], so[256], so[512], sr[768]);
+                const float4 bb = make_float4(sr[0], sr[256], sr[512], u2f(slot * (uint32_t)pl.nshadow + (uint32_t)k));
                 pl.q_sray_a[qi] = a; pl.q_sray_b[qi] = bb;
             }
         }
@@ -838,7 +842,7 @@ extern "C" int ptmi_upload_scene(ptmi_ctx *ctx, const PtMaterial *materials, uin
     const uint64_t ntris = ctx->tri_idx.size() / 3;
     if (!materials || !nmaterials || (!tri_material && ntris) || (!corner_normals && ntris) || !sky || (!lights && nlights))
         return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: null array");
-    // shade stages a path's shadow rays (one per light + 2) in LDS: 7 KB per ray kind beside the 32 KB of frames
+    // shade stages a path's shadow rays (one per light + 2) in LDS: 4 KB per ray kind beside the 32 KB of frames
     if (nlights > 16) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: at most 16 lights");
     for (uint64_t t = 0; t < ntris; ++t)
         if (tri_material[t] >= nmaterials) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: material index out of range");
@@ -1042,7 +1046,7 @@ static int lane_enqueue(ptmi_ctx *ctx, Lane &L, Lane *other, const DevScene &sc,
     if (nsr) launch_render_connect(ctx, pl, L.n_srays, L.st);
     if (other) { PTMI_HIP(ctx, hipEventRecord(L.ev_trav, L.st)); L.ev_recorded = true; }
     const uint32_t nshade = L.n_ext + L.n_shp;
-    const size_t ray_lds = (size_t)7 * pl.nshadow * 256 * sizeof(float);
+    const size_t ray_lds = (size_t)(6 + 4 * pl.nshadow) * 256 * sizeof(float);
     if (ray_lds > (28u << 10))      // beyond the default 64 KB of LDS per workgroup (gfx950 has 160 KB)
         PTMI_HIP(ctx, hipFuncSetAttribute((const void *)shade_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds));
     hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), ray_lds, L.st, pl, sc, ra, pl.q_ext[cur], L.n_ext,
