@@ -156,6 +156,25 @@ def render_leg(args, rank, world, dist, dev, torch):
         q[0] = mx[0]
     q = q.cpu().tolist()
     complete = bool((cnt == spp).all().item()) if rank == 0 else True
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the CPU oracle's integrator on a bounded part of the same frame: bands of 16 rows every 64, 8 samples per pixel
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        osc = oracle_lib.OracleScene(sc)
+        threads = max(1, min(16, os.cpu_count() or 1))
+        op = osc.params(W, H, bounces=2, scatter_rays=1, max_steps=1, ambient=p.ambient, step_size=1000.0, seed=1)
+        rows, spp_cpu, nsamp, t0, sb = 16, 8, 0, time.time(), 0
+        while time.time() - t0 < args.cpu_seconds * 0.6:          # passes of 8 more samples per pixel over the bands
+            for y0 in range(0, H, 64):
+                osc.render(sc.camera.as_array(), op, rect=(0, y0, W, min(rows, H - y0)), spp_begin=sb, spp_count=spp_cpu,
+                           nthreads=threads)
+                nsamp += W * min(rows, H - y0) * spp_cpu
+            sb += spp_cpu
+        dtc = time.time() - t0
+        cpu = {"value": round(nsamp / dtc / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+               "sample": f"{nsamp} samples of the same frame (bands of {rows} rows every 64, {sb} spp), {dtc:.1f} s, C "
+                         f"restatement of TraceRay with {threads} OpenMP threads"}
     return {"metric": "samples/s, full multi-bounce integrator", "value": round(W * H * spp / q[0] / 1e6, 2),
             "unit": "Msamples/s", "seconds": round(q[0], 4),
             "config": {"workload": "C3: blob + glass spheres + emissive quad + mirror sphere, gradient sky + sun "
@@ -163,7 +182,7 @@ def render_leg(args, rank, world, dist, dev, torch):
                        "triangles": int(sc.tris.shape[0]),
                        "sharding": "single GPU" if world == 1 else f"blocks of 8 rows round-robin over {world} ranks, one render call per rank + RCCL reduce"},
             "closest_hit_Mqueries_per_s": round(q[1] / q[0] / 1e6, 1), "any_hit_Mqueries_per_s": round(q[2] / q[0] / 1e6, 1),
-            "diffuse_events_M_per_s": round(q[3] / q[0] / 1e6, 1), "frame_complete": complete}
+            "diffuse_events_M_per_s": round(q[3] / q[0] / 1e6, 1), "frame_complete": complete, "cpu_baseline": cpu}
 
 
 def main():
