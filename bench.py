@@ -258,6 +258,21 @@ def main():
     else:
         total_rays = float(n)
 
+    # secondary: the any-hit (QuickCheckIntersection) form of the same batch, rank-local, outside the timed region
+    occ = torch.empty(n, dtype=torch.uint8, device=dev)
+    bvh.QuickCheckIntersectionDevice(wl["O"], wl["D"], wl["T"], occ, stream)
+    torch.cuda.synchronize()
+    ea0, ea1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ea0.record()
+    for _ in range(3):
+        bvh.QuickCheckIntersectionDevice(wl["O"], wl["D"], wl["T"], occ, stream)
+    ea1.record()
+    torch.cuda.synchronize()
+    any_ms = ea0.elapsed_time(ea1) / 3
+    any_hit = {"metric": "any-hit Mrays/s on the same batch (one GPU)", "value": round(n / any_ms / 1e3, 2), "unit": "Mrays/s",
+               "kernel": "connect_vote_kernel", "kernel_ms": round(any_ms, 4), "occluded_fraction": round(float(occ.float().mean().item()), 4)}
+    del occ
+
     render = None
     if not args.no_render:
         render = render_leg(args, rank, world, dist, dev, torch)
@@ -300,6 +315,7 @@ def main():
                          "l1_gather_peak_GBs": L1_GATHER_PEAK_GBS,
                          "frac_of_l1_gather_peak": round(achieved / L1_GATHER_PEAK_GBS, 4)},
         }
+        out["any_hit"] = any_hit
         if render is not None:
             out["render"] = render
         if world == 1 and not args.no_cpu_baseline:

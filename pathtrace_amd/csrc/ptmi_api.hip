@@ -192,6 +192,93 @@ __global__ __launch_bounds__(WAVE) void connect_kernel(DevBVH bvh, const float *
     flush_counters<COUNT>(cnt, counters, CNT_ANY, live ? 1u : 0u);
 }
 
+// The any-hit batch kernel, scheduled like extend_vote_kernel (persistent waves, one step type per iteration by
+// vote, rays dealt from one cursor in chunks, next ray prefetched).  Every ray walks its nodes in the order of
+// QuickCheckIntersection, so the work counters equal the reference walk's.
+template <int STACK, bool COUNT>
+__global__ __launch_bounds__(WAVE) void connect_vote_kernel(DevBVH bvh, const float *__restrict__ o,
+                                                            const float *__restrict__ d,
+                                                            const float *__restrict__ tmax, uint64_t n,
+                                                            uint8_t *__restrict__ occluded,
+                                                            unsigned long long *counters, unsigned long long *cursor,
+                                                            int refill_min, int tri_bias, uint32_t chunk_rays) {
+    __shared__ uint32_t smem[STACK * WAVE];
+    uint32_t *stack_base = smem + threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    TravCounters cnt;
+    RayTrav r;
+    r.cur = D_REF_DONE; r.exact = false; r.sp = 0; r.best = 0; r.best_t = 0.0f;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+    uint64_t my_ray = 0, next_ray = 0;
+    float nox = 0.f, noy = 0.f, noz = 0.f, ndx = 0.f, ndy = 0.f, ndz = 0.f, ntm = 0.f;
+    bool pending = false, have_next = false;
+    uint32_t nrays = 0;
+    auto grab = [&]() -> unsigned long long {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(cursor, (unsigned long long)chunk_rays);
+        return v;
+    };
+    auto uniform = [&](unsigned long long v) -> uint64_t {
+        return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+               (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    };
+    uint64_t chunk = uniform(grab()), chunk1 = uniform(grab());
+    unsigned long long inflight = grab();
+    uint32_t used = 0;
+    auto reserve = [&](uint32_t k) {
+        const uint64_t idx = k < chunk_rays ? chunk + k : chunk1 + (k - chunk_rays);
+        have_next = idx < n;
+        if (have_next) {
+            next_ray = idx;
+            nox = o[3 * idx]; noy = o[3 * idx + 1]; noz = o[3 * idx + 2];
+            ndx = d[3 * idx]; ndy = d[3 * idx + 1]; ndz = d[3 * idx + 2];
+            ntm = tmax[idx];
+        }
+    };
+    auto advance = [&](uint32_t taken) {
+        used += taken;
+        if (used >= chunk_rays) {
+            used -= chunk_rays;
+            chunk = chunk1;
+            chunk1 = uniform(inflight);
+            inflight = grab();
+        }
+    };
+    reserve(lane);
+    advance(WAVE);
+    for (;;) {
+        const bool at_inner = !(r.cur & D_REF_LEAF_BIT);
+        const bool at_tri = (r.cur & D_REF_LEAF_BIT) && r.cur != D_REF_DONE;
+        const bool idle = r.cur == D_REF_DONE;
+        const int nI = __popcll(__ballot(at_inner)), nT = __popcll(__ballot(at_tri));
+        const unsigned long long takers = __ballot(idle && have_next);
+        const int nR = __popcll(takers);
+        if (nI + nT == 0 || nR >= refill_min) {
+            if (idle && pending) { occluded[my_ray] = r.best ? 1 : 0; pending = false; }
+            if (nR == 0) break;
+            if (idle && have_next) {
+                my_ray = next_ray; pending = true; ++nrays;
+                trav_init(r, bvh, nox, noy, noz, ndx, ndy, ndz, ntm);
+                r.best = 0;
+                reserve(used + (uint32_t)__popcll(takers & lt_mask));
+            }
+            advance((uint32_t)nR);
+            continue;
+        }
+        if (nI > 0 && (nT == 0 || nI + tri_bias >= nT)) {
+            if (__any(at_inner && r.exact)) {
+                if (at_inner) vote_inner_step_any<WAVE, COUNT, true>(bvh, stack_base, r, cnt);
+            } else {
+                if (at_inner) vote_inner_step_any<WAVE, COUNT, false>(bvh, stack_base, r, cnt);
+            }
+        } else {
+            if (at_tri) vote_tri_step_any<WAVE, COUNT>(bvh, stack_base, r, cnt);
+        }
+    }
+    flush_counters<COUNT>(cnt, counters, CNT_ANY, nrays);
+}
+
 template <int STACK>
 static void launch_extend(ptmi_ctx *ctx, const float *o, const float *d, const float *tmax, uint64_t n, int32_t *prim,
                           float *t, hipStream_t s) {
@@ -224,12 +311,28 @@ template <int STACK>
 static void launch_connect(ptmi_ctx *ctx, const float *o, const float *d, const float *tmax, uint64_t n, uint8_t *occ,
                            hipStream_t s) {
     dim3 grid((unsigned)((n + WAVE - 1) / WAVE)), block(WAVE);
+    if (ctx->extend_variant == 0) {      // one-shot kernel (A/B reference, PTMI_EXTEND_VARIANT=0)
+        if (ctx->counting)
+            hipLaunchKernelGGL((connect_kernel<STACK, true>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
+                               ctx->d_counters);
+        else
+            hipLaunchKernelGGL((connect_kernel<STACK, false>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
+                               ctx->d_counters);
+        return;
+    }
+    int per_cu = 0;
+    const void *fn = ctx->counting ? (const void *)connect_vote_kernel<STACK, true> : (const void *)connect_vote_kernel<STACK, false>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WAVE, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+    per_cu = std::min(per_cu, ctx->persist_waves_per_cu);
+    unsigned long long *cursor = ctx->d_counters + CNT_CURSOR;
+    (void)hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s);
+    dim3 pgrid((unsigned)std::min<uint64_t>(grid.x, (uint64_t)ctx->num_cus * per_cu));
     if (ctx->counting)
-        hipLaunchKernelGGL((connect_kernel<STACK, true>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
-                           ctx->d_counters);
+        hipLaunchKernelGGL((connect_vote_kernel<STACK, true>), pgrid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
+                           ctx->d_counters, cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
     else
-        hipLaunchKernelGGL((connect_kernel<STACK, false>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
-                           ctx->d_counters);
+        hipLaunchKernelGGL((connect_vote_kernel<STACK, false>), pgrid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
+                           ctx->d_counters, cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
 }
 
 // ------------------------------------------------------------------------------------ context
