@@ -23,7 +23,6 @@ struct DevBVH {
     uint32_t dummy_tri;       // record empty leaves point at (degenerate, never hit); only the counters care
 };
 
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Packed node quarters: q0 = c0min.x c0max.x c1min.x c1max.x | q1 = same for y | q2 = same for z |
 // q3 = ref0 ref1 - -.  Child k's box is (q0[2k], q1[2k], q2[2k]) - (q0[2k+1], q1[2k+1], q2[2k+1]).
@@ -277,10 +276,10 @@ __device__ __forceinline__ void vote_inner_step(const DevBVH &bvh, uint32_t *sta
     }
 }
 
-// One triangle of a leaf (linear_bvh.go:129-137 + utils.go:63-125), all four dot products and both cross
-// products evaluated as packed-f32 pairs.  Every packed lane is the same single IEEE operation as the
-// scalar source line, in the same association order, so results are bit-identical; the early returns of
-// utils.go become one predicate (a NaN fails each `<`/`>` exactly as in the reference).
+// One triangle of a leaf (linear_bvh.go:129-137 + utils.go:63-125), branch-free: both cross products and all four
+// dot products are evaluated up front, each operation as the source line writes it, and the early returns of
+// utils.go become one predicate (a NaN fails each `<`/`>` exactly as in the reference).  Scalar f32 on purpose:
+// v_pk_mul/add_f32 issue at half rate on gfx950 (tools/ubench_pk.hip) and need extra moves.
 template <int BLOCK, bool COUNT>
 __device__ __forceinline__ void vote_tri_step(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
     const float EPS = (float)1e-6;
@@ -289,23 +288,16 @@ __device__ __forceinline__ void vote_tri_step(const DevBVH &bvh, uint32_t *stack
     const float4 *p = bvh.tris + (size_t)rec * 3;
     const float4 r0 = p[0], r1 = p[1], r2 = p[2];
     const float ax = r1.z, ay = r1.w, az = r2.x;
-    const f2 ex = f2{r0.x, r0.y} - f2{ax, ax};          // (edge1.x, edge2.x)   utils.go:70-71
-    const f2 ey = f2{r0.z, r0.w} - f2{ay, ay};
-    const f2 ez = f2{r1.x, r1.y} - f2{az, az};
-    const f2 vx = {r.ox - ax, r.dx};                    // (tvec.x, dir.x)      utils.go:91
-    const f2 vy = {r.oy - ay, r.dy};
-    const f2 vz = {r.oz - az, r.dz};
-    // (qvec, pvec) = (tvec x edge1, dir x edge2)        utils.go:103-107, :77-81
-    const f2 cx = vy * ez - vz * ey;
-    const f2 cy = vz * ex - vx * ez;
-    const f2 cz = vx * ey - vy * ex;
-    const f2 sx = __builtin_shufflevector(cx, cx, 1, 0), sy = __builtin_shufflevector(cy, cy, 1, 0),
-             sz = __builtin_shufflevector(cz, cz, 1, 0);            // (pvec, qvec)
-    const f2 m = (ex * sx + ey * sy) + ez * sz;         // (det = edge1.pvec, edge2.qvec)   utils.go:83, :116
-    const f2 k = (vx * sx + vy * sy) + vz * sz;         // (tvec.pvec, dir.qvec)            utils.go:93, :108
-    const float det = m.x;
-    const float inv = 1.0f / det;                       // utils.go:88
-    const float u = k.x * inv, v = k.y * inv, t = m.y * inv;
+    const float e1x = r0.x - ax, e1y = r0.z - ay, e1z = r1.x - az;      // edge1 = B - A    utils.go:70
+    const float e2x = r0.y - ax, e2y = r0.w - ay, e2z = r1.y - az;      // edge2 = C - A    utils.go:71
+    const float px = r.dy * e2z - r.dz * e2y, py = r.dz * e2x - r.dx * e2z, pz = r.dx * e2y - r.dy * e2x;   // :77-81
+    const float det = (e1x * px + e1y * py) + e1z * pz;                 // :83
+    const float inv = 1.0f / det;                                       // :88
+    const float tx = r.ox - ax, ty = r.oy - ay, tz = r.oz - az;         // :91
+    const float u = ((tx * px + ty * py) + tz * pz) * inv;              // :93
+    const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;               // :103-107
+    const float v = ((r.dx * qx + r.dy * qy) + r.dz * qz) * inv;        // :108
+    const float t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;           // :116
     bool hit = !(fabsf(det) < EPS);                                          // :84-86
     hit = hit && !(u < -EPS || u > ONE_PLUS_EPS);                            // :96-98
     hit = hit && !(v < -EPS || u + v > ONE_PLUS_EPS);                        // :111-113
