@@ -143,6 +143,43 @@ def test_row_shards_sum_to_the_frame(gpu_ctx):
         r.render_rows_device(ref, refc, p, sc.camera, shard=2, nshards=2)
 
 
+def test_full_size_frame_properties(gpu_ctx):
+    """BASELINE.json configs[2] geometry at full resolution (1920x1080, C3 scene, 16 M-path pool), checked through
+    properties: a re-run is bit-identical (queue order and atomics play no part in the sums), two half sample
+    ranges continue each other exactly, the row shards of two "ranks" sum to the frame, every pixel got its samples,
+    and the image agrees with the CPU oracle on a band of rows."""
+    import torch
+    sc = scenes.bunny_scene(blob_level=6, glass=True, emissive=True)
+    W, H, spp = 1920, 1080, 16
+    p = make_params(W, H, bounces=2, seed=1)
+    r = Renderer(sc, ctx=gpu_ctx)
+    dev = torch.device("cuda", 0)
+
+    def frame():
+        return (torch.zeros((H, W, 3), dtype=torch.float32, device=dev), torch.zeros((H, W), dtype=torch.int32, device=dev))
+
+    a, c = frame(); r.render_device(a, c, p, sc.camera, spp=spp)
+    b, cb = frame(); r.render_device(b, cb, p, sc.camera, spp=spp)
+    assert torch.equal(a, b) and torch.equal(c, cb) and bool((c == spp).all())
+    assert bool(torch.isfinite(a).all()) and float(a.min()) >= 0.0
+    h2, ch2 = frame()
+    r.render_device(h2, ch2, p, sc.camera, spp=spp // 2)
+    r.render_device(h2, ch2, p, sc.camera, spp=spp // 2, spp_begin=spp // 2)
+    assert torch.equal(a, h2) and torch.equal(c, ch2)
+    tot, totc = frame()
+    for rank in range(2):
+        s_, sc_ = frame()
+        r.render_rows_device(s_, sc_, p, sc.camera, shard=rank, nshards=2, row_block=8, spp=spp)
+        tot += s_; totc += sc_
+    assert torch.equal(a, tot) and torch.equal(c, totc)
+    # the oracle on rows 536..543
+    osc = oracle_lib.OracleScene(sc)
+    acc, cnt, _ = osc.render(sc.camera.as_array(), _oparams(p), rect=(0, 536, W, 8), spp_count=spp)
+    band = a[536:544].cpu().numpy()
+    rmse = np.sqrt(((band - acc) ** 2).mean()) / spp
+    assert rmse <= IMAGE_RMSE_TOL * (acc / spp).mean(), (rmse, (acc / spp).mean())
+
+
 def test_frame_loop_writes_frames(gpu_ctx, tmp_path):
     """driver.frame_loop = main.go:832-941 without the window: 4x4 tiles, PNG per frame, orbiting camera."""
     from pathtrace_amd import driver

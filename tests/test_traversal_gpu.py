@@ -122,3 +122,67 @@ def test_golden_vectors_on_gpu(gpu_ctx, path):
     c = bvh.counters()
     bvh.set_counting(False)
     assert [c.inner_visits, c.tri_tests, c.leaf_visits] == g["closest_counters"].tolist()
+
+
+def test_full_size_batch_properties(gpu_ctx, monkeypatch):
+    """BASELINE.json configs[1] at full size (1 M triangles, 16.7 M primary + secondary rays), checked through
+    properties that need no full CPU pass: the vote-scheduled and the one-shot kernels (two independent
+    implementations) agree bit for bit on every ray, results do not depend on batch order or on a re-run, every hit
+    lies in (0, tmax], and a 1-in-64 sample equals the oracle."""
+    import torch
+    from pathtrace_amd import Context
+    v, f = scenes.make_soup(1_000_000, seed=42)
+    box = BuildBVH(v, f)
+    bvh = ConstructLinearBVH(box, ctx=gpu_ctx)
+    monkeypatch.setenv("PTMI_EXTEND_VARIANT", "0")
+    ctx0 = Context(0)                                     # a second context that runs the one-shot kernels
+    monkeypatch.delenv("PTMI_EXTEND_VARIANT")
+    bvh0 = ConstructLinearBVH(box, ctx=ctx0)
+    cam = scenes.soup_camera(v)
+    o1, d1 = scenes.camera_rays(cam, 4096, 2048)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def closest(b, o, d, tmax):
+        n = o.shape[0]
+        O, D = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+        T = torch.full((n,), tmax, dtype=torch.float32, device=dev)
+        P = torch.empty(n, dtype=torch.int32, device=dev); t = torch.empty(n, dtype=torch.float32, device=dev)
+        occ = torch.empty(n, dtype=torch.uint8, device=dev)
+        b.CheckIntersectionDevice(O, D, T, P, t, st)
+        b.QuickCheckIntersectionDevice(O, D, T, occ, st)
+        torch.cuda.synchronize()
+        return P.cpu().numpy(), t.cpu().numpy(), occ.cpu().numpy()
+
+    p1, t1, _ = closest(bvh, o1, d1, 1000.0)
+    o2, d2 = scenes.cosine_bounce_rays(v, f, o1, d1, p1, t1, seed=42)
+    o = np.concatenate([o1, o2], 0); d = np.concatenate([d1, d2], 0)
+    n = o.shape[0]
+    assert n == 1 << 24
+    P, T, OCC = closest(bvh, o, d, 1000.0)
+    # (1) two kernels, one answer
+    P0, T0, OCC0 = closest(bvh0, o, d, 1000.0)
+    assert np.array_equal(P, P0) and bits_equal(T, T0) and np.array_equal(OCC, OCC0)
+    # (2) idempotent, and independent of the order of the batch (scheduling, refill and chunking play no part)
+    Pb, Tb, OCCb = closest(bvh, o, d, 1000.0)
+    assert np.array_equal(P, Pb) and bits_equal(T, Tb) and np.array_equal(OCC, OCCb)
+    perm = np.random.default_rng(5).permutation(n)[: 1 << 22]
+    Pp, Tp, OCCp = closest(bvh, np.ascontiguousarray(o[perm]), np.ascontiguousarray(d[perm]), 1000.0)
+    assert np.array_equal(Pp, P[perm]) and bits_equal(Tp, T[perm]) and np.array_equal(OCCp, OCC[perm])
+    # (3) range: hits lie in (0, tmax], misses report t = 0 and prim = -1; ids are valid triangles
+    hit = P >= 0
+    assert 0.3 < hit.mean() < 0.95
+    assert (T[hit] > 0).all() and (T[hit] <= 1000.0).all() and (T[~hit] == 0).all() and (P[~hit] == -1).all()
+    assert P.max() < f.shape[0]
+    # (4) a shorter segment can only lose hits beyond it: same answer where t <= tmax', a miss or a nearer hit otherwise
+    sub = np.arange(0, n, 16)
+    Ps, Ts, _ = closest(bvh, np.ascontiguousarray(o[sub]), np.ascontiguousarray(d[sub]), 3.0)
+    near = hit[sub] & (T[sub] <= 3.0)
+    assert np.array_equal(Ps[near], P[sub][near]) and bits_equal(Ts[near], T[sub][near])
+    assert (Ps[~near] == -1).all()
+    # (5) the oracle on every 64th ray
+    idx = np.arange(0, n, 64)
+    orc = oracle_lib.OracleBVH(v, f, linear=box.linear())
+    op, ot, _ = orc.closest_hit(np.ascontiguousarray(o[idx]), np.ascontiguousarray(d[idx]), 1000.0)
+    oocc, _ = orc.any_hit(np.ascontiguousarray(o[idx]), np.ascontiguousarray(d[idx]), 1000.0)
+    assert np.array_equal(P[idx], op) and bits_equal(T[idx], ot) and np.array_equal(OCC[idx].astype(bool), oocc)
