@@ -93,7 +93,7 @@ struct Pool {
     float4 *hdr;                         // [cap][HQ]           header
     float4 *fr;                          // [cap][nframes][8]   frames (F_*)
     float *trk;                          // [cap][ntrk]         RefractiveIndexTracker.indices
-    float4 *sh;                          // [cap][nshadow]      (contribution.xyz, occluded as u32 bits)
+    float4 *sh;                          // [cap][nframes][nshadow]  (contribution.xyz, occluded as u32 bits) per frame
     // queues
     uint32_t *q_ext[2];                  // extend queue (double buffered): slots ...
     float4 *q_ext_ray[2];                // ... and their rays, 2 x float4 per entry: (o.xyz, bits(slot)) / (d.xyz, -)
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool p
         TravCounters tc;
         bool occ = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc);
         const uint32_t target = f2u(bb.w);
-        if (target < pl.cap * (uint32_t)pl.nshadow) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = occ ? 1u : 0u;
+        if (target < pl.cap * (uint32_t)pl.nframes * (uint32_t)pl.nshadow) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = occ ? 1u : 0u;
         else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
     }
     if (threadIdx.x == 0 && blk * WAVE < n) {
@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     bool want_extend = false, want_shadow = false, finished = false;
     uint32_t n_sray = 0;                       // shadow rays this path wants to enqueue
     uint32_t need_out = 0;                     // their slots (bit k = shadow slot k)
+    int stage_depth = 0;                       // depth of the frame that cast them (its shadow slots take the answers)
     uint32_t diffuse_events = 0;
     V3 out_o = mk(0, 0, 0), out_d = mk(0, 0, 0);   // the ray of a path that wants an extend (goes into its queue entry)
     if (live) {
@@ -330,7 +331,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         // arguments of a child call pushed in this invocation (they go into the header when the path parks)
         int arg_bounces = 0, arg_bindex = 0; uint32_t arg_flags = 0; float arg_energy = 0.0f; V3 arg_ln = mk(0, 0, 0);
         float4 *frames = pl.fr + (size_t)slot * pl.nframes * 8;
-        float4 *shp = pl.sh + (size_t)slot * pl.nshadow;
+        // shadow slots of the frame at depth `dep`
+        auto shp_at = [&](int dep) -> float4 * { return pl.sh + ((size_t)slot * pl.nframes + dep) * pl.nshadow; };
 
         // The top frame lives in LDS, [word][thread] (conflict-free): it is read and written all over the state
         // machine below, and 32 more loop-carried registers per lane are what this kernel cannot afford.
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 uint32_t need = 0;
                 auto stage = [&](int k, V3 o, V3 d, float range, V3 contrib) {
                     need |= 1u << k;
-                    shp[k] = make_float4(contrib.x, contrib.y, contrib.z, u2f(0u));
+                    shp_at(depth)[k] = make_float4(contrib.x, contrib.y, contrib.z, u2f(0u));
                     float *so = s_ray + (k == pl.nshadow - 1 ? 3 : 0) * 256 + tid;     // rewritten per ray: same value
                     so[0] = o.x; so[256] = o.y; so[512] = o.z;
                     float *sr = s_ray + (size_t)(6 + 4 * k) * 256 + tid;
@@ -558,29 +560,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     }
                 }
                 FU_SET(F_NEED, need);
-                if (need) { FU_SET(F_PHASE, PH_SHADOW_WAIT); store_frame(depth); need_out = need; want_shadow = true; break; }
-                state = ST_SHADOW_DONE; continue;
+                need_out = need; stage_depth = depth;
+                // A frame with a GI child to wait for anyway does not park for its shadow rays: they are traced while
+                // the child is, and their answers are read in ST_DIFFUSE_FINAL (same draws, same sums, one visit less).
+                if (need && FI(F_BOUNCES) <= 0) { FU_SET(F_PHASE, PH_SHADOW_WAIT); store_frame(depth); want_shadow = true; break; }
+                state = FI(F_BOUNCES) > 0 ? ST_GI_LOOP : ST_DIFFUSE_FINAL; continue;                // :622
             }
             if (state == ST_SHADOW_DONE) {
-                if (!have_hit) { load_hit(h); have_hit = true; }
-                const V3 albedo = h.albedo;
-                const uint32_t need = FU(F_NEED);
-                V3 direct = mk(0, 0, 0);
-                auto term = [&](int k) -> V3 {          // contribution of shadow slot k if it was cast and not occluded
-                    if (!(need >> k & 1u)) return mk(0, 0, 0);
-                    const float4 v = shp[k];
-                    return f2u(v.w) == 0u ? mk(v.x, v.y, v.z) : mk(0, 0, 0);
-                };
-                if (sc.sky.kind != PTMI_SKY_NONE && (need & 1u)) {                                  // :538-540
-                    const float4 v = shp[0];
-                    if (f2u(v.w) == 0u) direct = add(direct, mk(v.x, v.y, v.z));
-                }
-                for (uint32_t li = 0; li < sc.nlights; ++li)                                        // :557-559
-                    direct = add(direct, cmul(albedo, term(1 + (int)li)));
-                if (sc.nemissive > 0) direct = add(direct, term(1 + (int)sc.nlights));              // :617
-                FV_SET(F_DIRECT, direct);
-                if (FI(F_BOUNCES) > 0) { state = ST_GI_LOOP; continue; }                            // :622
-                state = ST_DIFFUSE_FINAL; continue;
+                state = FI(F_BOUNCES) > 0 ? ST_GI_LOOP : ST_DIFFUSE_FINAL; continue;
             }
             if (state == ST_GI_LOOP) {                                                              // :636-647
                 if (!have_hit) { load_hit(h); have_hit = true; }
@@ -601,7 +588,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if (!have_hit) { load_hit(h); have_hit = true; }
                 const PtMaterial &m = sc.mats[h.mat];
                 V3 indirect = FI(F_BOUNCES) > 0 ? FV(F_SUM) : mk(0, 0, 0);
-                V3 fin = FV(F_DIRECT);
+                // direct lighting from the answers of this frame's shadow rays
+                const V3 albedo = h.albedo;
+                const uint32_t need = FU(F_NEED);
+                const float4 *shp = shp_at(depth);
+                V3 direct = mk(0, 0, 0);
+                auto term = [&](int k) -> V3 {          // contribution of shadow slot k if it was cast and not occluded
+                    if (!(need >> k & 1u)) return mk(0, 0, 0);
+                    const float4 v = shp[k];
+                    return f2u(v.w) == 0u ? mk(v.x, v.y, v.z) : mk(0, 0, 0);
+                };
+                if (sc.sky.kind != PTMI_SKY_NONE && (need & 1u)) {                                  // :538-540
+                    const float4 v = shp[0];
+                    if (f2u(v.w) == 0u) direct = add(direct, mk(v.x, v.y, v.z));
+                }
+                for (uint32_t li = 0; li < sc.nlights; ++li)                                        // :557-559
+                    direct = add(direct, cmul(albedo, term(1 + (int)li)));
+                if (sc.nemissive > 0) direct = add(direct, term(1 + (int)sc.nlights));   // :617
+                V3 fin = direct;
                 fin = add(fin, scale(h.albedo, ra.p.ambient));
                 fin = add(fin, scale(indirect, 1.0f));
                 if (FI(F_BINDEX) == 0 && is_emissive(m)) fin = add(fin, mk(m.ke));
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const float *so = s_ray + (k == pl.nshadow - 1 ? 3 : 0) * 256 + threadIdx.x;
                 const float *sr = s_ray + (size_t)(6 + 4 * k) * 256 + threadIdx.x;
                 const float4 a = make_float4(so[0], so[256], so[512], sr[768]);
-                const float4 bb = make_float4(sr[0], sr[256], sr[512], u2f(slot * (uint32_t)pl.nshadow + (uint32_t)k));
+                const float4 bb = make_float4(sr[0], sr[256], sr[512], u2f((slot * (uint32_t)pl.nframes + (uint32_t)stage_depth) * (uint32_t)pl.nshadow + (uint32_t)k));
                 pl.q_sray_a[qi] = a; pl.q_sray_b[qi] = bb;
             }
         }
@@ -938,7 +942,7 @@ static int tracker_words(int bounces) {
 // device bytes one path of the pool takes (records + its share of every queue)
 static uint64_t pool_bytes_per_path(int bounces, int nlights) {
     const uint64_t nframes = (uint64_t)bounces + 1, nshadow = (uint64_t)nlights + 2;
-    return 128 + 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 + 32) * nshadow + 4 * 5 + 32 * 2;
+    return 128 + 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 * nframes + 32) * nshadow + 4 * 5 + 32 * 2;
 }
 
 static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
@@ -955,7 +959,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     for (int l = 0; l < lanes; ++l) {
         Off &o = of[l];
         o.hdr = carve(off, 128 * c); o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
-        o.sh = carve(off, 16 * c * nshadow);
+        o.sh = carve(off, 16 * c * nshadow * (size_t)nframes);
         o.qe0 = carve(off, 4 * c); o.qe1 = carve(off, 4 * c); o.qs0 = carve(off, 4 * c); o.qs1 = carve(off, 4 * c);
         o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow);
         o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
@@ -1121,7 +1125,8 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     // that wait for their longest rays, one host round trip), so the pool is as large as the work and the memory
     // budget allow: 2 M paths reach 640 Msamples/s on C3, 16 M reach 760 (profiles/r01c/README.md).
     const uint64_t path_bytes = pool_bytes_per_path(bounces, (int)rs->nlights);
-    const uint64_t by_budget = std::max<uint64_t>(1u << 16, ctx->pool_bytes_max / path_bytes);
+    const uint64_t by_targets = 0xFFFFFFFFull / ((uint64_t)(bounces + 1) * (rs->nlights + 2));   // shadow slot ids are 32-bit
+    const uint64_t by_budget = std::min(by_targets, std::max<uint64_t>(1u << 16, ctx->pool_bytes_max / path_bytes));
     uint32_t cap = (uint32_t)std::min<uint64_t>({(max_total + lanes - 1) / lanes, (uint64_t)ctx->pool_paths / (uint64_t)lanes,
                                                  by_budget / (uint64_t)lanes});
     cap = (cap + 255) / 256 * 256;
