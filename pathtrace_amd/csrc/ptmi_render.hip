@@ -947,9 +947,9 @@ static uint64_t pool_bytes_per_path(int bounces, int nlights) {
 
 static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     RenderState *rs = ctx->render;
-    if (rs->pool_mem && rs->pool_cap == cap && rs->pool_bounces == bounces && rs->pool_nlights == (int)rs->nlights &&
+    if (rs->pool_mem && rs->pool_cap >= cap && rs->pool_bounces == bounces && rs->pool_nlights == (int)rs->nlights &&
         rs->pool_lanes == lanes)
-        return PTMI_OK;
+        return PTMI_OK;                  // a larger pool of the same shape serves (tiles of different sizes)
     if (rs->pool_mem) { (void)hipFree(rs->pool_mem); rs->pool_mem = nullptr; }
     const int nframes = bounces + 1, nshadow = (int)rs->nlights + 2;
     const int ntrk = tracker_words(bounces);
@@ -965,7 +965,11 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
         o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
         o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * QC_COUNT * QC_STRIDE);
     }
-    PTMI_HIP(ctx, hipMalloc((void **)&rs->pool_mem, off));
+    if (hipMalloc((void **)&rs->pool_mem, off) != hipSuccess) {
+        (void)hipGetLastError();
+        rs->pool_mem = nullptr; rs->pool_cap = 0;
+        return PTMI_ERR_OOM;
+    }
     rs->pool_bytes = off;
     char *b = rs->pool_mem;
     for (int l = 0; l < lanes; ++l) {
@@ -1130,13 +1134,18 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     uint32_t cap = (uint32_t)std::min<uint64_t>({(max_total + lanes - 1) / lanes, (uint64_t)ctx->pool_paths / (uint64_t)lanes,
                                                  by_budget / (uint64_t)lanes});
     cap = (cap + 255) / 256 * 256;
-    int rc = ensure_pool(ctx, cap, bounces, lanes);
-    if (rc) return rc;
+    // the per-sample output buffer first (its size is fixed by the request), then as large a pool as fits
     if (rs->out_bytes < max_total * 12) {
-        if (rs->d_out) { (void)hipFree(rs->d_out); rs->d_out = nullptr; }
+        if (rs->d_out) { (void)hipFree(rs->d_out); rs->d_out = nullptr; rs->out_bytes = 0; }
         PTMI_HIP(ctx, hipMalloc((void **)&rs->d_out, max_total * 12));
         rs->out_bytes = max_total * 12;
     }
+    int rc;
+    while ((rc = ensure_pool(ctx, cap, bounces, lanes)) == PTMI_ERR_OOM && cap > (1u << 16))
+        cap = (cap / 2 + 255) / 256 * 256;          // device memory is short (other contexts on this GPU): halve
+    if (rc == PTMI_ERR_OOM) return set_err(ctx, PTMI_ERR_OOM, "ptmi_render: out of device memory for the path pool");
+    if (rc) return rc;
+    cap = rs->pool_cap;
     if (!rs->lane_stream) {
         PTMI_HIP(ctx, hipStreamCreateWithFlags(&rs->lane_stream, hipStreamNonBlocking));
         PTMI_HIP(ctx, hipEventCreateWithFlags(&rs->ev_begin, hipEventDisableTiming));
