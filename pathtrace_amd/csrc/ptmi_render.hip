@@ -53,7 +53,7 @@ struct ShadowCounts { uint32_t n[NSB]; };
 // Path header, 32 words = one 128-byte line per slot (8 x float4):
 //   q0  sample id, RNG key, RNG counter, packed (depth | tracker length << 8 | HP_PENDING)
 //   q1  tracker entry 0, hit status, hit primitive, hit t            (words 1-3 are written by extend)
-//   q2  V_t at the start of the geodesic, V_t now, ray origin x y    q3  origin z, direction
+//   q2  V_t at the start of the geodesic, V_t now (written by extend)   q3  -   (the current ray lives in the extend queue entry)
 //   q4  arguments of the pending TraceRay call: bounces, bounceIndex, flags, energy     q5  lastSurfaceNormal
 //   q6, q7  tracker entries 1-8 (deeper histories continue in Pool::trk)
 // HP_PENDING: the top of the recursion stack is a TraceRay call that has not looked at its hit yet.  Such a
@@ -95,8 +95,7 @@ struct Pool {
     float *trk;                          // [cap][ntrk]         RefractiveIndexTracker.indices
     float4 *sh;                          // [cap][nframes][nshadow]  (contribution.xyz, occluded as u32 bits) per frame
     // queues
-    uint32_t *q_ext[2];                  // extend queue (double buffered): slots ...
-    float4 *q_ext_ray[2];                // ... and their rays, 2 x float4 per entry: (o.xyz, bits(slot)) / (d.xyz, -)
+    float4 *q_ext_ray[2];                // extend queue (double buffered), 2 x float4 per entry: (o.xyz, bits(slot)) / (d.xyz, -)
     uint32_t *q_shpath[2];               // paths waiting for their shadow rays
     float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, bits(index into sh))
     uint32_t *q_free;                    // slots that finished in the last shade pass
@@ -126,10 +125,9 @@ __device__ __forceinline__ int32_t f2i(float f) { return __float_as_int(f); }
 // ------------------------------------------------------------------------------------------ generate
 // main.go:861-874 + the TraceRay call of :875 (bounceIndex 0, lastSurfaceNormal {}, not specular,
 // NewRefractiveIndexTracker(1.0), energy 1.0)
-// Every generated path goes to the extend queue, so its queue position needs no atomic: q_ext_next[q_base + i].
+// Every generated path goes to the extend queue, so its queue position needs no atomic: entry q_base + i.
 __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, const uint32_t *slots, uint32_t n,
-                                                       uint64_t first_sample, uint32_t *q_ext_next, float4 *q_ray_next,
-                                                       uint32_t q_base) {
+                                                       uint64_t first_sample, float4 *q_ray_next, uint32_t q_base) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool live = i < n;
     uint32_t slot = 0;
@@ -175,7 +173,6 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, c
     }
     // TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0; shade handles that case
     if (live) {
-        q_ext_next[q_base + i] = slot;
         float4 *qr = q_ray_next + 2 * (size_t)(q_base + i);
         qr[0] = make_float4(gen_o.x, gen_o.y, gen_o.z, u2f(slot));
         qr[1] = make_float4(gen_d.x, gen_d.y, gen_d.z, 0.0f);
@@ -186,10 +183,10 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, c
 // The march loop of TraceRay (tracer.go:33-35, 226-256): closest hit on the segment [0, stepSize];
 // on a miss advance (straight) or RK4-step the geodesic (curved) and test the horizon.
 // Queue entries carry the ray, so the kernel reads them coalesced and never reads the (scattered) path header;
-// it writes the hit into the header, and the ray only when the march moved it.
+// it writes the hit into the header, and the ray back into its queue entry only when the march moved it.
 template <int STACK, bool CURVED>
 __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl, DevScene sc, RenderArgs ra,
-                                                             const float4 *__restrict__ qray, uint32_t n,
+                                                             float4 *__restrict__ qray, uint32_t n,
                                                              unsigned long long *counters) {
     __shared__ uint32_t smem[STACK * WAVE];
     uint32_t i = blockIdx.x * WAVE + threadIdx.x;
@@ -225,10 +222,11 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
         }
         float *h1 = (float *)(hd + 1);                                             // word 0 (tracker length) is shade's
         h1[1] = i2f(status); h1[2] = i2f(prim); h1[3] = t;
-        if (CURVED || moved) {
-            hd[2] = make_float4(vt0, st.vt, o.x, o.y);
-            hd[3] = make_float4(o.z, d.x, d.y, d.z);
+        if (CURVED || moved) {               // shade reads the ray from this entry (same index in its list)
+            qray[2 * (size_t)i] = make_float4(o.x, o.y, o.z, qa.w);
+            qray[2 * (size_t)i + 1] = make_float4(d.x, d.y, d.z, 0.0f);
         }
+        if (CURVED) { float *h2 = (float *)(hd + 2); h2[0] = vt0; h2[1] = st.vt; }
     }
     for (int off = 32; off > 0; off >>= 1) nq += __shfl_xor(nq, off);
     if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)nq);
@@ -287,9 +285,9 @@ __device__ __forceinline__ bool is_emissive(const PtMaterial &m) { return m.ke[0
 // States of the per-path machine inside one shade invocation.
 enum { ST_EXTENDED, ST_MATERIAL, ST_SHADOW_DONE, ST_GI_LOOP, ST_REFL_LOOP, ST_DIFFUSE_FINAL, ST_COMBINE, ST_RETURN };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, const uint32_t *list_a,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, const float4 *list_a,
                                                     uint32_t na, const uint32_t *list_b, uint32_t nb,
-                                                    uint32_t *q_ext_next, float4 *q_ray_next, uint32_t *q_shpath_next,
+                                                    float4 *q_ray_next, uint32_t *q_shpath_next,
                                                     unsigned long long *qc_ext_next, unsigned long long *qc_shp_next,
                                                     unsigned long long *counters) {
     __shared__ float s_fw[FRW * 256];
@@ -308,11 +306,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     uint32_t diffuse_events = 0;
     V3 out_o = mk(0, 0, 0), out_d = mk(0, 0, 0);   // the ray of a path that wants an extend (goes into its queue entry)
     if (live) {
-        slot = i < na ? list_a[i] : list_b[i - na];
+        // list_a = the extend queue's entries (ray + slot) in the order extend answered them, list_b = slots
+        float4 qa = make_float4(0, 0, 0, 0), qb = qa;
+        if (i < na) { qa = list_a[2 * (size_t)i]; qb = list_a[2 * (size_t)i + 1]; slot = f2u(qa.w); }
+        else slot = list_b[i - na];
         uint32_t err = 0;
         if (slot >= pl.cap) { err = ERR_SLOT; slot = 0; }
         float4 *hd = pl.hdr + (size_t)slot * HQ;
-        const float4 h0 = hd[0], h1 = hd[1], h2 = hd[2], h3 = hd[3], h4 = hd[4], h5 = hd[5];
+        const float4 h0 = hd[0], h1 = hd[1], h2 = hd[2], h4 = hd[4], h5 = hd[5];
         const uint32_t sid = f2u(h0.x);
         Rng rng; rng.key = f2u(h0.y); rng.ctr = f2u(h0.z);
         const uint32_t packed = f2u(h0.w);
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         float trk0 = h1.x;
         const int hs = f2i(h1.y), hprim = f2i(h1.z);
         const float ht = h1.w, vt0 = h2.x, vt1 = h2.y;
-        V3 cur_o = mk(h2.z, h2.w, h3.x), cur_d = mk(h3.y, h3.z, h3.w);      // the path's current ray
+        V3 cur_o = mk(qa.x, qa.y, qa.z), cur_d = mk(qb.x, qb.y, qb.z);      // the path's current ray (pending calls only)
         float *hw = (float *)hd;
         float *trk = pl.trk + (size_t)slot * pl.ntrk;
         // arguments of a child call pushed in this invocation (they go into the header when the path parks)
@@ -680,8 +681,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             hd[0] = make_float4(h0.x, h0.y, u2f(rng.ctr), u2f((uint32_t)depth | trk_len << 8 | (want_extend ? HP_PENDING : 0u)));
             hd[1] = make_float4(trk0, h1.y, h1.z, h1.w);
             if (want_extend) {
-                hd[2] = make_float4(h2.x, h2.y, cur_o.x, cur_o.y);
-                hd[3] = make_float4(cur_o.z, cur_d.x, cur_d.y, cur_d.z);
                 hd[4] = make_float4(i2f(arg_bounces), i2f(arg_bindex), u2f(arg_flags), arg_energy);
                 hd[5] = make_float4(arg_ln.x, arg_ln.y, arg_ln.z, 0.0f);
                 out_o = cur_o; out_d = cur_d;
@@ -735,7 +734,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __syncthreads();
         if (want_extend) {
             const uint32_t pe = s_q[0][wv] + (uint32_t)__popcll(m_ext & lt);
-            q_ext_next[pe] = slot;
             q_ray_next[2 * (size_t)pe] = make_float4(out_o.x, out_o.y, out_o.z, u2f(slot));
             q_ray_next[2 * (size_t)pe + 1] = make_float4(out_d.x, out_d.y, out_d.z, 0.0f);
         }
@@ -942,7 +940,7 @@ static int tracker_words(int bounces) {
 // device bytes one path of the pool takes (records + its share of every queue)
 static uint64_t pool_bytes_per_path(int bounces, int nlights) {
     const uint64_t nframes = (uint64_t)bounces + 1, nshadow = (uint64_t)nlights + 2;
-    return 128 + 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 * nframes + 32) * nshadow + 4 * 5 + 32 * 2;
+    return 128 + 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 * nframes + 32) * nshadow + 4 * 3 + 32 * 2;
 }
 
 static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
@@ -954,13 +952,13 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     const int nframes = bounces + 1, nshadow = (int)rs->nlights + 2;
     const int ntrk = tracker_words(bounces);
     const size_t c = cap;
-    struct Off { size_t hdr, fr, trk, sh, qe0, qe1, qs0, qs1, ra, rb, qr0, qr1, free_, cnt; } of[2];
+    struct Off { size_t hdr, fr, trk, sh, qs0, qs1, ra, rb, qr0, qr1, free_, cnt; } of[2];
     size_t off = 0;
     for (int l = 0; l < lanes; ++l) {
         Off &o = of[l];
         o.hdr = carve(off, 128 * c); o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
         o.sh = carve(off, 16 * c * nshadow * (size_t)nframes);
-        o.qe0 = carve(off, 4 * c); o.qe1 = carve(off, 4 * c); o.qs0 = carve(off, 4 * c); o.qs1 = carve(off, 4 * c);
+        o.qs0 = carve(off, 4 * c); o.qs1 = carve(off, 4 * c);
         o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow);
         o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
         o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * QC_COUNT * QC_STRIDE);
@@ -978,7 +976,6 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
         p.cap = cap; p.nframes = nframes; p.nshadow = nshadow; p.ntrk = ntrk;
         p.hdr = (float4 *)(b + o.hdr); p.fr = (float4 *)(b + o.fr); p.trk = (float *)(b + o.trk);
         p.sh = (float4 *)(b + o.sh);
-        p.q_ext[0] = (uint32_t *)(b + o.qe0); p.q_ext[1] = (uint32_t *)(b + o.qe1);
         p.q_ext_ray[0] = (float4 *)(b + o.qr0); p.q_ext_ray[1] = (float4 *)(b + o.qr1);
         p.q_shpath[0] = (uint32_t *)(b + o.qs0); p.q_shpath[1] = (uint32_t *)(b + o.qs1);
         p.q_sray_a = (float4 *)(b + o.ra); p.q_sray_b = (float4 *)(b + o.rb);
@@ -990,7 +987,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
 }
 
 template <int STACK>
-static void launch_render_extend_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, const float4 *qray,
+static void launch_render_extend_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, float4 *qray,
                                    uint32_t n, hipStream_t s) {
     if (sc.has_bh)
         hipLaunchKernelGGL((render_extend_kernel<STACK, true>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
@@ -999,7 +996,7 @@ static void launch_render_extend_t(ptmi_ctx *ctx, const Pool &pl, const DevScene
         hipLaunchKernelGGL((render_extend_kernel<STACK, false>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
                            pl, sc, ra, qray, n, ctx->d_counters);
 }
-static void launch_render_extend(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, const float4 *qray,
+static void launch_render_extend(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, float4 *qray,
                                  uint32_t n, hipStream_t s) {
     const int dep = ctx->max_depth;      // the LDS stack is as deep as the tree
     if (dep <= 16) launch_render_extend_t<16>(ctx, pl, sc, ra, qray, n, s);
@@ -1057,8 +1054,8 @@ static int lane_enqueue(ptmi_ctx *ctx, Lane &L, Lane *other, const DevScene &sc,
     const size_t ray_lds = (size_t)(6 + 4 * pl.nshadow) * 256 * sizeof(float);
     if (ray_lds > (28u << 10))      // beyond the default 64 KB of LDS per workgroup (gfx950 has 160 KB)
         PTMI_HIP(ctx, hipFuncSetAttribute((const void *)shade_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds));
-    hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), ray_lds, L.st, pl, sc, ra, pl.q_ext[cur], L.n_ext,
-                       pl.q_shpath[cur], L.n_shp, pl.q_ext[cur ^ 1], pl.q_ext_ray[cur ^ 1], pl.q_shpath[cur ^ 1],
+    hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), ray_lds, L.st, pl, sc, ra, pl.q_ext_ray[cur], L.n_ext,
+                       pl.q_shpath[cur], L.n_shp, pl.q_ext_ray[cur ^ 1], pl.q_shpath[cur ^ 1],
                        qc(QC_EXT0 + (cur ^ 1)), qc(QC_SHP0 + (cur ^ 1)), ctx->d_counters);
     PTMI_HIP(ctx, hipGetLastError());
     PTMI_HIP(ctx, hipMemcpyAsync(L.hc, pl.qcnt, qc_bytes, hipMemcpyDeviceToHost, L.st));
@@ -1085,7 +1082,7 @@ static int lane_finish(ptmi_ctx *ctx, Lane &L, const RenderArgs &ra) {
     if (n_free && L.next_sample < L.end_sample) {
         const uint32_t ng = (uint32_t)std::min<uint64_t>(n_free, L.end_sample - L.next_sample);
         hipLaunchKernelGGL(generate_kernel, dim3((ng + 255) / 256), dim3(256), 0, L.st, pl, ra, (const uint32_t *)pl.q_free, ng,
-                           L.next_sample, pl.q_ext[nxt], pl.q_ext_ray[nxt], ne);
+                           L.next_sample, pl.q_ext_ray[nxt], ne);
         PTMI_HIP(ctx, hipGetLastError());
         L.next_sample += ng;
         ne += ng;
@@ -1187,7 +1184,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             const uint32_t n0 = (uint32_t)std::min<uint64_t>(cap, L[l].end_sample - L[l].next_sample);
             if (n0) {
                 hipLaunchKernelGGL(generate_kernel, dim3((n0 + 255) / 256), dim3(256), 0, L[l].st, L[l].pl, ra,
-                                   (const uint32_t *)nullptr, n0, L[l].next_sample, L[l].pl.q_ext[0], L[l].pl.q_ext_ray[0], 0u);
+                                   (const uint32_t *)nullptr, n0, L[l].next_sample, L[l].pl.q_ext_ray[0], 0u);
                 PTMI_HIP(ctx, hipGetLastError());
             }
             L[l].next_sample += n0;
