@@ -57,6 +57,23 @@ def test_point_light_solid_sky_ambient_and_marching(gpu_ctx):
     _compare_samples(sc, p, 2, gpu_ctx)
 
 
+def test_many_lights(gpu_ctx):
+    """9 lights = 11 shadow-ray kinds: more than the 8 queue buckets (the last bucket takes several kinds per path) and
+    more staged rays than the default 64 KB of LDS per workgroup holds."""
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    lights = [sc.lights[0]]
+    for k in range(8):
+        a = 0.7 * k
+        lights.append(scenes.point_light((2.5 * np.cos(a), 2.0 + 0.2 * k, 2.5 * np.sin(a)), 12.0, (1.0, 0.6 + 0.05 * k, 0.5)))
+    sc.lights = np.stack(lights).astype(np.float32)
+    p = make_params(48, 48, bounces=2, seed=8)
+    _compare_samples(sc, p, 2, gpu_ctx)
+    # 17 lights are refused (the staging area is sized for 16)
+    sc.lights = np.stack([lights[1]] * 17).astype(np.float32)
+    with pytest.raises(Exception):
+        Renderer(sc, ctx=gpu_ctx)
+
+
 def test_no_sky_and_image_sky(gpu_ctx):
     sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
     sc.sky = scenes.sky_none()
