@@ -48,6 +48,13 @@ def test_samples_match_oracle(gpu_ctx, glass, emissive, bounces, scatter):
     _compare_samples(sc, p, 4, gpu_ctx)
 
 
+def test_deep_recursion(gpu_ctx):
+    """bounces = 7: eight frames per path, the 64-entry tracker history (entries beyond 8 leave the header)."""
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    p = make_params(32, 32, bounces=7, seed=13)
+    _compare_samples(sc, p, 2, gpu_ctx)
+
+
 def test_point_light_solid_sky_ambient_and_marching(gpu_ctx):
     sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
     sc.lights = np.stack([sc.lights[0], scenes.point_light((1.5, 3.0, 2.0), 40.0, (1.0, 0.8, 0.6))]).astype(np.float32)
