@@ -234,6 +234,12 @@ int ptmi_render_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *param
 int ptmi_render_rows_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t row_block,
                          int32_t shard, int32_t nshards, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
                          uint32_t *counts, void *stream);
+/* Several tiles of tile.go's split in ONE call (the reference starts a goroutine per tile, main.go:935-937; a shim
+ * collects them): tiles_xywh[4*k..] = (x0, y0, w, h) of tile k, disjoint, all rendered in one wavefront pass and added
+ * into FULL-FRAME device buffers as above.  The sums are those of one ptmi_render_dev call per tile, bit for bit. */
+int ptmi_render_tiles_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t ntiles,
+                          const int32_t *tiles_xywh, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
+                          uint32_t *counts, void *stream);
 /* Per-sample radiance without accumulation: out[(pixel*spp_count + s)*3], host buffer. */
 int ptmi_render_samples(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t x0, int32_t y0,
                         int32_t w, int32_t h, uint32_t spp_begin, uint32_t spp_count, float *out_rgb);

@@ -82,6 +82,9 @@ struct RenderArgs {
     // row m of the region is image row y0 + (m / row_block) * row_period + m % row_block: a plain rectangle has
     // row_block = row_period = h, a row-interleaved shard (ptmi_render_rows_dev) takes every nshards-th block of rows
     int row_block, row_period;
+    // a list of tiles (ptmi_render_tiles_dev) instead: pixel p of the region belongs to tile k with
+    // tile_first[k] <= p < tile_first[k+1], row-major inside tile_rect[k] = (x0, y0, w, h)
+    const uint32_t *tile_first; const int4 *tile_rect; uint32_t ntiles;
     uint32_t spp_begin, spp_chunk;       // this batch covers samples [spp_begin, spp_begin+spp_chunk) of every pixel
     uint64_t total;                      // w*h*spp_chunk
 };
@@ -122,6 +125,24 @@ __device__ __forceinline__ float i2f(int32_t i) { return __int_as_float(i); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ int32_t f2i(float f) { return __float_as_int(f); }
 
+// image pixel of the region's pixel number `pix`
+__device__ __forceinline__ void region_pixel(const RenderArgs &ra, uint32_t pix, int &X, int &Y) {
+    if (ra.ntiles) {
+        uint32_t lo = 0, hi = ra.ntiles - 1;                   // last tile whose first pixel is <= pix
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (ra.tile_first[mid] <= pix) lo = mid; else hi = mid - 1;
+        }
+        const int4 r = ra.tile_rect[lo];
+        const uint32_t q = pix - ra.tile_first[lo];
+        X = r.x + (int)(q % (uint32_t)r.z); Y = r.y + (int)(q / (uint32_t)r.z);
+        return;
+    }
+    const int m = (int)(pix / (uint32_t)ra.w);
+    X = ra.x0 + (int)(pix % (uint32_t)ra.w);
+    Y = ra.y0 + (m / ra.row_block) * ra.row_period + m % ra.row_block;
+}
+
 // ------------------------------------------------------------------------------------------ generate
 // main.go:861-874 + the TraceRay call of :875 (bounceIndex 0, lastSurfaceNormal {}, not specular,
 // NewRefractiveIndexTracker(1.0), energy 1.0)
@@ -137,8 +158,8 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, c
         slot = slots ? slots[i] : i;
         const uint32_t sid = (uint32_t)first_sample + i;                   // total < 2^32/3 (render_core)
         uint32_t pix = sid / ra.spp_chunk, s = sid % ra.spp_chunk;
-        const int m = (int)(pix / (uint32_t)ra.w);
-        int X = ra.x0 + (int)(pix % (uint32_t)ra.w), Y = ra.y0 + (m / ra.row_block) * ra.row_period + m % ra.row_block;
+        int X, Y;
+        region_pixel(ra, pix, X, Y);
         Rng rng = rng_init(ra.p.seed, (uint32_t)(Y * ra.p.width + X), ra.spp_begin + s);
         float rx = ((float)X + rng_f32(rng)) / (float)ra.p.width;
         float ry = ((float)Y + rng_f32(rng)) / (float)ra.p.height;
@@ -774,8 +795,8 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float *out, uint3
     if (p >= npix) return;
     size_t q = p;
     if (frame_width > 0) {
-        const int m = (int)(p / (uint32_t)ra.w), x = ra.x0 + (int)(p % (uint32_t)ra.w);
-        const int y = ra.y0 + (m / ra.row_block) * ra.row_period + m % ra.row_block;
+        int x, y;
+        region_pixel(ra, p, x, y);
         q = (size_t)y * (size_t)frame_width + (size_t)x;
     }
     float r = accum[3 * q], g = accum[3 * q + 1], b = accum[3 * q + 2];
@@ -807,6 +828,7 @@ struct RenderState {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_trav[2] = {nullptr, nullptr};
     unsigned long long *h_qc = nullptr;  // pinned, 2 x QC_COUNT * QC_STRIDE words
     float *d_out = nullptr; size_t out_bytes = 0;
+    char *d_tiles = nullptr; size_t tiles_bytes = 0;   // tile list of ptmi_render_tiles_dev
     float *d_accum = nullptr; uint32_t *d_counts = nullptr; size_t accum_pix = 0;
 };
 
@@ -815,7 +837,7 @@ void free_scene(ptmi_ctx *ctx) {
     RenderState *rs = ctx->render;
     if (!rs) return;
     void *ptrs[] = {rs->d_uvs, rs->d_tex, rs->d_tex_pixels, rs->d_stri, rs->d_mats, rs->d_emissive, rs->d_lights,
-                    rs->d_sky_img, rs->pool_mem, rs->d_out, rs->d_accum, rs->d_counts};
+                    rs->d_sky_img, rs->pool_mem, rs->d_out, rs->d_accum, rs->d_counts, rs->d_tiles};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (rs->lane_stream) (void)hipStreamDestroy(rs->lane_stream);
     if (rs->ev_begin) (void)hipEventDestroy(rs->ev_begin);
@@ -1098,15 +1120,17 @@ static int lane_finish(ptmi_ctx *ctx, Lane &L, const RenderArgs &ra) {
 // row_period = row_block * shards, and d_accum / d_counts are full frames).
 static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, int x0, int y0, int w, int h,
                        uint32_t spp_begin, uint32_t spp_count, float *d_accum, uint32_t *d_counts, float *out_samples_host,
-                       hipStream_t s, int row_block = 0, int row_period = 0) {
+                       hipStream_t s, int row_block = 0, int row_period = 0, const uint32_t *d_tile_first = nullptr,
+                       const int4 *d_tile_rect = nullptr, uint32_t ntiles = 0) {
     RenderState *rs = ctx->render;
     if (!rs || !rs->have_scene) return set_err(ctx, PTMI_ERR_NO_SCENE, "ptmi_render: no scene uploaded");
     if (!cam || !prm) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: null camera / params");
-    const bool rows_mode = row_block > 0;
-    if (w <= 0 || h <= 0 || prm->width <= 0 || prm->height <= 0 || x0 < 0 || y0 < 0 || x0 + w > prm->width ||
+    // a tile list: (x0, y0, w, h) = (0, 0, region pixels, 1), validated by the caller
+    const bool rows_mode = row_block > 0 || ntiles > 0;
+    if (w <= 0 || h <= 0 || prm->width <= 0 || prm->height <= 0 || x0 < 0 || y0 < 0 || (!ntiles && x0 + w > prm->width) ||
         (!rows_mode && y0 + h > prm->height))
         return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: rectangle outside the image");
-    if (!rows_mode) { row_block = h; row_period = h; }
+    if (!rows_mode || ntiles) { row_block = h; row_period = h; }
     else if (y0 + ((h - 1) / row_block) * row_period + (h - 1) % row_block >= prm->height)
         return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: row shard outside the image");
     if (prm->bounces > 30 || prm->scatter_rays < 1 || prm->max_steps < 0)
@@ -1163,6 +1187,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         RenderArgs ra{};
         ra.cam = *cam; ra.p = *prm; ra.x0 = x0; ra.y0 = y0; ra.w = w; ra.h = h;
         ra.row_block = row_block; ra.row_period = row_period;
+        ra.tile_first = d_tile_first; ra.tile_rect = d_tile_rect; ra.ntiles = ntiles;
         ra.spp_begin = spp_begin + done; ra.spp_chunk = chunk; ra.total = npix * chunk;
 
         // lane 1's stream joins the caller's stream here and hands back at the end of the chunk
@@ -1258,6 +1283,48 @@ extern "C" int ptmi_render_rows_dev(ptmi_ctx *ctx, const PtCamera *camera, const
                          counts, nullptr, (hipStream_t)stream, row_block, row_block * nshards);
     if (rc) return rc;
     PTMI_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_render_tiles_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t ntiles,
+                                     const int32_t *tiles_xywh, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
+                                     uint32_t *counts, void *stream) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_render_tiles_dev: ctx is null");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_render_tiles_dev: no BVH");
+    RenderState *rs = ctx->render;
+    if (!rs || !rs->have_scene) return set_err(ctx, PTMI_ERR_NO_SCENE, "ptmi_render_tiles_dev: no scene uploaded");
+    if (!accum_rgb || !counts || !params || (ntiles && !tiles_xywh))
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_tiles_dev: null argument");
+    if (ntiles == 0) return PTMI_OK;
+    std::vector<uint32_t> first(ntiles + 1);
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < ntiles; ++k) {
+        const int32_t *t = tiles_xywh + 4 * (size_t)k;
+        if (t[2] <= 0 || t[3] <= 0 || t[0] < 0 || t[1] < 0 || (int64_t)t[0] + t[2] > params->width || (int64_t)t[1] + t[3] > params->height)
+            return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_tiles_dev: tile " + std::to_string(k) + " is empty or outside the image");
+        first[k] = (uint32_t)total;
+        total += (uint64_t)t[2] * (uint64_t)t[3];
+        if (total > (uint64_t)params->width * (uint64_t)params->height)
+            return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_tiles_dev: the tiles cover more pixels than the image has (overlap)");
+    }
+    first[ntiles] = (uint32_t)total;
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t b_first = ((size_t)(ntiles + 1) * 4 + 15) / 16 * 16, b_rect = (size_t)ntiles * 16;
+    if (rs->tiles_bytes < b_first + b_rect) {
+        if (rs->d_tiles) { (void)hipFree(rs->d_tiles); rs->d_tiles = nullptr; rs->tiles_bytes = 0; }
+        PTMI_HIP(ctx, hipMalloc((void **)&rs->d_tiles, b_first + b_rect));
+        rs->tiles_bytes = b_first + b_rect;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    PTMI_HIP(ctx, hipMemcpyAsync(rs->d_tiles, first.data(), (size_t)(ntiles + 1) * 4, hipMemcpyHostToDevice, s));
+    PTMI_HIP(ctx, hipMemcpyAsync(rs->d_tiles + b_first, tiles_xywh, b_rect, hipMemcpyHostToDevice, s));
+    PTMI_HIP(ctx, hipStreamSynchronize(s));                 // `first` is a local
+    // the region is handed to render_core as a 1-row strip of `total` pixels; region_pixel() maps them to the tiles
+    if (total > 0x7FFFFFFFull) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_tiles_dev: too many pixels");
+    int rc = render_core(ctx, camera, params, 0, 0, (int)total, 1, spp_begin, spp_count, accum_rgb, counts, nullptr, s, 0, 0,
+                         (const uint32_t *)rs->d_tiles, (const int4 *)(rs->d_tiles + b_first), ntiles);
+    if (rc) return rc;
+    PTMI_HIP(ctx, hipStreamSynchronize(s));
     return PTMI_OK;
 }
 

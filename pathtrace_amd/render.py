@@ -132,6 +132,16 @@ class Renderer:
         check(self._lib.ptmi_render_rows_dev(self.ctx.handle, C.byref(cam), C.byref(params), row_block, shard, nshards,
                                              spp_begin, spp, accum.data_ptr(), counts.data_ptr(), s), self.ctx.handle)
 
+    def render_tiles_device(self, accum, counts, params: PtParams, camera, tiles, spp=32, spp_begin=0, stream=None):
+        """Several disjoint tiles [(x0, y0, w, h), ...] in one call, added into FULL-FRAME torch CUDA tensors."""
+        cam = camera if isinstance(camera, PtCamera) else make_camera(camera)
+        assert tuple(accum.shape) == (params.height, params.width, 3) and accum.is_contiguous()
+        assert tuple(counts.shape) == (params.height, params.width) and counts.is_contiguous()
+        t = np.ascontiguousarray(np.asarray(tiles, np.int32).reshape(-1, 4))
+        s = C.c_void_p(stream) if stream else None
+        check(self._lib.ptmi_render_tiles_dev(self.ctx.handle, C.byref(cam), C.byref(params), t.shape[0], _ptr(t, C.c_int32),
+                                              spp_begin, spp, accum.data_ptr(), counts.data_ptr(), s), self.ctx.handle)
+
     def render_samples(self, params: PtParams, camera, rect=None, spp=1, spp_begin=0):
         """Per-sample radiance [h,w,spp,3] (no accumulation) -- for fine-grained parity checks."""
         cam = camera if isinstance(camera, PtCamera) else make_camera(camera)

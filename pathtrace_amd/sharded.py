@@ -4,7 +4,7 @@ The reference already renders a frame as independent tiles, one goroutine per ti
 A GPU wants its whole share in ONE call (every wavefront iteration costs ~0.3 ms whatever the number of paths in
 it, so a 64x64 tile never fills the machine): `mode="rows"` deals blocks of `row_block` rows round-robin to ranks
 (`(y // row_block) % world == rank`, rendered by ptmi_render_rows_dev in one pass); `mode="tile"` keeps the
-reference's granularity (`tile_id % world == rank`, one call per merged tile strip).  Every
+reference's granularity (`tile_id % world == rank`; all of a rank's tiles in one ptmi_render_tiles_dev call).  Every
 rank adds its share into a zero-initialised full-frame accumulator, which is then summed onto `dst` with one
 `torch.distributed.reduce` (backend "nccl" = RCCL over xGMI; 4K frame = 99.5 MB + 33 MB of counts).  Regions are
 disjoint, so the reduced sums are bit-identical to a single-GPU render (x + 0 == x).  RNG streams are keyed by
@@ -53,7 +53,7 @@ def merge_rects(rects):
 
 
 def render_sharded(render_rect, accum, counts, width, height, spp, rank=0, world=1, dist=None, dst=0, mode="tile",
-                   tile=64, group=None, render_rows=None, row_block=8):
+                   tile=64, group=None, render_rows=None, row_block=8, render_tiles=None):
     """Render this rank's shard with `render_rect(rect, spp_begin, spp)` (which must ADD into the rows/cols of the
     full-frame tensors `accum` [H,W,3] / `counts` [H,W] it is given views of) and reduce onto `dst`.
 
@@ -62,8 +62,13 @@ def render_sharded(render_rect, accum, counts, width, height, spp, rank=0, world
     accum.zero_()
     counts.zero_()
     if mode == "tile":
-        for (x0, y0, w, h) in my_tiles(width, height, world, rank, tile):
-            render_rect(accum, counts, (x0, y0, w, h), 0, spp)
+        mine = my_tiles(width, height, world, rank, tile)
+        if render_tiles is not None:           # all of this rank's tiles in one call (ptmi_render_tiles_dev)
+            if mine:
+                render_tiles(accum, counts, mine, 0, spp)
+        else:
+            for (x0, y0, w, h) in mine:
+                render_rect(accum, counts, (x0, y0, w, h), 0, spp)
     elif mode == "rows":
         # render_rows(accum, counts, shard, nshards, row_block, spp_begin, spp_count): one call for the whole share
         if render_rows is None:
@@ -99,6 +104,14 @@ def make_device_render_rect(renderer, params, camera, stream=None):
         counts[y0:y0 + h, x0:x0 + w] += c
 
     return render_rect
+
+
+def make_device_render_tiles(renderer, params, camera, stream=None):
+    """render_tiles callable for the real backend (ptmi_render_tiles_dev on full-frame CUDA tensors)."""
+    def render_tiles(accum, counts, tiles, spp_begin, spp_count):
+        renderer.render_tiles_device(accum, counts, params, camera, tiles, spp_count, spp_begin, stream)
+
+    return render_tiles
 
 
 def make_device_render_rows(renderer, params, camera, stream=None):

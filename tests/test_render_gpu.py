@@ -167,6 +167,33 @@ def test_row_shards_sum_to_the_frame(gpu_ctx):
         r.render_rows_device(ref, refc, p, sc.camera, shard=2, nshards=2)
 
 
+def test_tiles_in_one_call(gpu_ctx):
+    """ptmi_render_tiles_dev: a list of tiles rendered in one wavefront pass gives the sums of one call per tile."""
+    import torch
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    W, H, spp = 80, 56, 3
+    p = make_params(W, H, bounces=2, seed=6)
+    r = Renderer(sc, ctx=gpu_ctx)
+    dev = torch.device("cuda", 0)
+    ref = torch.zeros((H, W, 3), dtype=torch.float32, device=dev); refc = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    r.render_device(ref, refc, p, sc.camera, spp=spp)
+    tiles = sharded.tile_rects(W, H, 32)                      # ragged right and bottom edges
+    a = torch.zeros_like(ref); c = torch.zeros_like(refc)
+    r.render_tiles_device(a, c, p, sc.camera, tiles, spp=spp)
+    assert torch.equal(a, ref) and torch.equal(c, refc)
+    # a rank's share of the tiles: its pixels get their samples, the others stay untouched
+    mine = sharded.my_tiles(W, H, 3, 1, 32)
+    a.zero_(); c.zero_()
+    r.render_tiles_device(a, c, p, sc.camera, mine, spp=spp)
+    mask = torch.zeros((H, W), dtype=torch.bool, device=dev)
+    for (x0, y0, w, h) in mine:
+        mask[y0:y0 + h, x0:x0 + w] = True
+    assert torch.equal(a[mask], ref[mask]) and bool((c[mask] == spp).all()) and bool((c[~mask] == 0).all())
+    for bad in ([(0, 0, W + 1, 8)], [(0, 0, 0, 8)], [(0, 0, W, H), (0, 0, 8, 8)]):
+        with pytest.raises(Exception):
+            r.render_tiles_device(a, c, p, sc.camera, bad, spp=1)
+
+
 def test_full_size_frame_properties(gpu_ctx):
     """BASELINE.json configs[2] geometry at full resolution (1920x1080, C3 scene, 16 M-path pool), checked through
     properties: a re-run is bit-identical (queue order and atomics play no part in the sums), two half sample
