@@ -38,6 +38,30 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class _HostStagedDist:
+    """torch.distributed over gloo for the rehearsal mode: gloo has no CUDA `reduce`, so tensors go through the host."""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def barrier(self):
+        self._d.barrier()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
+
+    def all_reduce(self, t, op=None):
+        h = t.cpu()
+        self._d.all_reduce(h, op=op)
+        t.copy_(h)
+
+    def reduce(self, t, dst=0, op=None, group=None):
+        h = t.cpu()
+        self._d.reduce(h, dst=dst, op=op, group=group)
+        t.copy_(h)
+
+
 def build_workload(args, rank, torch, dev):
     """Mesh + BVH + ray batch, all untimed set-up.  Returns dict with device tensors."""
     from pathtrace_amd import BuildBVH, ConstructLinearBVH, Context, scenes
@@ -207,13 +231,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    # PTMI_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- exercises the world > 1 code on a one-GPU box (RCCL
+    # refuses two ranks on one device); the numbers of such a run mean nothing
+    rehearse = os.environ.get("PTMI_BENCH_REHEARSE") == "1"
+    dev = torch.device("cuda", 0 if rehearse else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist = _HostStagedDist(dist)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     wl = build_workload(args, rank, torch, dev)
     bvh, n = wl["bvh"], wl["n"]
@@ -315,6 +346,8 @@ def main():
                          "l1_gather_peak_GBs": L1_GATHER_PEAK_GBS,
                          "frac_of_l1_gather_peak": round(achieved / L1_GATHER_PEAK_GBS, 4)},
         }
+        if rehearse:
+            out["rehearsal"] = "all ranks share cuda:0 over gloo: exercises the world > 1 code, not a measurement"
         out["any_hit"] = any_hit
         if render is not None:
             out["render"] = render
