@@ -160,7 +160,7 @@ def render_leg(args, rank, world, dist, dev, torch):
         # every rank renders its row-interleaved share of the frame in one call, then one reduce onto rank 0
         sharded.render_sharded(None, acc, cnt, W, H, spp_, rank=rank, world=world, dist=dist, dst=0, mode="rows",
                                render_rows=rows, row_block=8)
-    run(1)                                   # warm-up: pool allocation, RCCL channel set-up
+    run(spp)                                 # warm-up at full size: path pool and sample buffer allocation, RCCL channel set-up
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

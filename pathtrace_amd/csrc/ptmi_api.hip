@@ -365,6 +365,8 @@ extern "C" int ptmi_create(int device, ptmi_ctx **out) {
         if (const char *v = getenv("PTMI_POOL_PATHS")) ctx->pool_paths = std::max(1 << 16, std::min(1 << 26, atoi(v)));
         if (const char *v = getenv("PTMI_POOL_GIB")) ctx->pool_bytes_max = (uint64_t)std::max(1, atoi(v)) << 30;
         if (const char *v = getenv("PTMI_RENDER_LANES")) ctx->render_lanes = atoi(v);
+        if (const char *v = getenv("PTMI_CONNECT_BAIL")) ctx->connect_bail_lanes = atoi(v);
+        if (const char *v = getenv("PTMI_CHUNK_MSAMPLES")) ctx->chunk_msamples = std::max(1, std::min(1024, atoi(v)));
         if (const char *v = getenv("PTMI_VOTE_CHUNK")) ctx->vote_chunk = std::max(64, atoi(v) / 64 * 64);
     }
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||

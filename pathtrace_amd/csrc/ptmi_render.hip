@@ -50,6 +50,11 @@ enum { HS_MISS = 0, HS_HIT = 1, HS_HORIZON = 2 };
 enum { NSB = 8 };
 enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHP0 = 2, QC_SHP1 = 3, QC_FREE = 4, QC_SRAY = 5, QC_COUNT = QC_SRAY + NSB, QC_STRIDE = 16 };
 struct ShadowCounts { uint32_t n[NSB]; };
+// connect's retry queue: a wave whose last few lanes are still walking hands their rays to a second launch.  The queue
+// is split into RETRY_SHARDS regions, each with a counter on a line of its own (same-line atomics serialise); wave w
+// appends to region w % RETRY_SHARDS, at most BAIL_MAX rays, so a region of ceil(waves / RETRY_SHARDS) * BAIL_MAX
+// entries cannot overflow.  The counters follow the queue counters (one memset clears both).
+enum { RETRY_SHARDS = 256, BAIL_MAX = 16 };
 // Path header, 32 words = one 128-byte line per slot (8 x float4):
 //   q0  sample id, RNG key, RNG counter, packed (depth | tracker length << 8 | HP_PENDING)
 //   q1  tracker entry 0, hit status, hit primitive, hit t            (words 1-3 are written by extend)
@@ -101,6 +106,7 @@ struct Pool {
     float4 *q_ext_ray[2];                // extend queue (double buffered), 2 x float4 per entry: (o.xyz, bits(slot)) / (d.xyz, -)
     uint32_t *q_shpath[2];               // paths waiting for their shadow rays
     float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, bits(index into sh))
+    uint32_t *q_retry; uint32_t retry_shard_cap;   // shadow rays a connect wave gave up on (RETRY_SHARDS regions), see connect
     uint32_t *q_free;                    // slots that finished in the last shade pass
     unsigned long long *qcnt;            // QC_COUNT counters, QC_STRIDE words apart
     float *out;                          // per-sample radiance [total][3]
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
 // Bucket b's rays sit at q_sray[b * cap ...]; workgroups are dealt to the buckets in order.
 template <int STACK>
 __global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool pl, ShadowCounts sn,
-                                                              unsigned long long *counters) {
+                                                              unsigned long long *counters, int bail_lanes) {
     __shared__ uint32_t smem[STACK * WAVE];
     uint32_t blk = blockIdx.x, b = 0, n = 0;
     bool found = false;
@@ -270,16 +276,46 @@ __global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool p
     if (j < n) {
         const size_t i = (size_t)b * pl.cap + j;
         const float4 a = pl.q_sray_a[i], bb = pl.q_sray_b[i];
-        TravCounters tc;
-        bool occ = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc);
+        int res;
+        if (bail_lanes > 0) {
+            res = any_hit_or_bail<WAVE>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, bail_lanes);
+        } else {
+            TravCounters tc;
+            res = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc) ? 1 : 0;
+        }
         const uint32_t target = f2u(bb.w);
-        if (target < pl.cap * (uint32_t)pl.nframes * (uint32_t)pl.nshadow) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = occ ? 1u : 0u;
-        else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
+        if (target >= pl.cap * (uint32_t)pl.nframes * (uint32_t)pl.nshadow) atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
+        else if (res < 2) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = (uint32_t)res;
+        // the wave's stragglers: one atomic on this wave's retry region, then the ray numbers
+        const uint32_t shard = blockIdx.x % RETRY_SHARDS;
+        const uint32_t pos = wave_append(pl.qcnt + (size_t)(QC_COUNT + shard) * QC_STRIDE, res == 2);
+        if (res == 2) {
+            if (pos < pl.retry_shard_cap) pl.q_retry[(size_t)shard * pl.retry_shard_cap + pos] = (uint32_t)i;
+            else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
+        }
     }
     if (threadIdx.x == 0 && blk * WAVE < n) {
         uint32_t cnt = min((uint32_t)WAVE, n - blk * WAVE);
         atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)cnt);
     }
+}
+
+// Second launch: the rays the first one gave up on, region by region, in full waves, walked to the end.
+template <int STACK>
+__global__ __launch_bounds__(WAVE) void render_connect_retry_kernel(DevBVH bvh, Pool pl, unsigned long long *counters) {
+    __shared__ uint32_t smem[STACK * WAVE];
+    const uint32_t shard = blockIdx.x % RETRY_SHARDS, k = blockIdx.x / RETRY_SHARDS;
+    const uint32_t n = min((uint32_t)pl.qcnt[(size_t)(QC_COUNT + shard) * QC_STRIDE], pl.retry_shard_cap);
+    const uint32_t j = k * WAVE + threadIdx.x;
+    if (j >= n) return;
+    const size_t i = pl.q_retry[(size_t)shard * pl.retry_shard_cap + j];
+    if (i >= (size_t)pl.cap * (size_t)pl.nshadow) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT); return; }
+    const float4 a = pl.q_sray_a[i], bb = pl.q_sray_b[i];
+    TravCounters tc;
+    const bool occ = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc);
+    const uint32_t target = f2u(bb.w);
+    if (target < pl.cap * (uint32_t)pl.nframes * (uint32_t)pl.nshadow) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = occ ? 1u : 0u;
+    else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
 }
 
 // ------------------------------------------------------------------------------------------ shade
@@ -962,7 +998,7 @@ static int tracker_words(int bounces) {
 // device bytes one path of the pool takes (records + its share of every queue)
 static uint64_t pool_bytes_per_path(int bounces, int nlights) {
     const uint64_t nframes = (uint64_t)bounces + 1, nshadow = (uint64_t)nlights + 2;
-    return 128 + 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 * nframes + 32) * nshadow + 4 * 3 + 32 * 2;
+    return 128 + 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 * nframes + 32) * nshadow + 4 * 3 + 32 * 2 + nshadow;
 }
 
 static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
@@ -974,7 +1010,9 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     const int nframes = bounces + 1, nshadow = (int)rs->nlights + 2;
     const int ntrk = tracker_words(bounces);
     const size_t c = cap;
-    struct Off { size_t hdr, fr, trk, sh, qs0, qs1, ra, rb, qr0, qr1, free_, cnt; } of[2];
+    struct Off { size_t hdr, fr, trk, sh, qs0, qs1, ra, rb, qr0, qr1, free_, cnt, retry; } of[2];
+    // connect launches at most cap * nshadow / 64 + NSB waves
+    const size_t retry_shard_cap = (((size_t)cap * nshadow / WAVE + NSB) / RETRY_SHARDS + 1) * BAIL_MAX;
     size_t off = 0;
     for (int l = 0; l < lanes; ++l) {
         Off &o = of[l];
@@ -983,7 +1021,8 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
         o.qs0 = carve(off, 4 * c); o.qs1 = carve(off, 4 * c);
         o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow);
         o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
-        o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * QC_COUNT * QC_STRIDE);
+        o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * (QC_COUNT + RETRY_SHARDS) * QC_STRIDE);
+        o.retry = carve(off, 4 * retry_shard_cap * RETRY_SHARDS);
     }
     if (hipMalloc((void **)&rs->pool_mem, off) != hipSuccess) {
         (void)hipGetLastError();
@@ -1002,6 +1041,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
         p.q_shpath[0] = (uint32_t *)(b + o.qs0); p.q_shpath[1] = (uint32_t *)(b + o.qs1);
         p.q_sray_a = (float4 *)(b + o.ra); p.q_sray_b = (float4 *)(b + o.rb);
         p.q_free = (uint32_t *)(b + o.free_); p.qcnt = (unsigned long long *)(b + o.cnt);
+        p.q_retry = (uint32_t *)(b + o.retry); p.retry_shard_cap = (uint32_t)retry_shard_cap;
         rs->pools[l] = p;
     }
     rs->pool_cap = cap; rs->pool_bounces = bounces; rs->pool_nlights = (int)rs->nlights; rs->pool_lanes = lanes;
@@ -1031,7 +1071,14 @@ template <int STACK>
 static void launch_render_connect_t(ptmi_ctx *ctx, const Pool &pl, const ShadowCounts &n, hipStream_t s) {
     unsigned blocks = 0;
     for (int b = 0; b < NSB; ++b) blocks += (n.n[b] + WAVE - 1) / WAVE;
-    hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(blocks), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n, ctx->d_counters);
+    const int bail = std::max(0, std::min((int)BAIL_MAX, ctx->connect_bail_lanes));
+    hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(blocks), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n, ctx->d_counters, bail);
+    if (bail > 0) {
+        // a region holds at most ceil(blocks / RETRY_SHARDS) * bail rays; workgroups beyond a region's count leave at once
+        const unsigned per_shard = ((blocks + RETRY_SHARDS - 1) / RETRY_SHARDS * (unsigned)bail + WAVE - 1) / WAVE;
+        hipLaunchKernelGGL((render_connect_retry_kernel<STACK>), dim3(per_shard * RETRY_SHARDS), dim3(WAVE), 0, s, ctx->dev_bvh(), pl,
+                           ctx->d_counters);
+    }
 }
 static void launch_render_connect(ptmi_ctx *ctx, const Pool &pl, const ShadowCounts &n, hipStream_t s) {
     const int dep = ctx->max_depth;
@@ -1065,7 +1112,7 @@ static int lane_enqueue(ptmi_ctx *ctx, Lane &L, Lane *other, const DevScene &sc,
     const size_t qc_bytes = (size_t)QC_COUNT * QC_STRIDE * sizeof(unsigned long long);
     auto qc = [&](int which) { return pl.qcnt + (size_t)which * QC_STRIDE; };
     const int cur = L.cur;
-    PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, qc_bytes, L.st));
+    PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, qc_bytes + (size_t)RETRY_SHARDS * QC_STRIDE * sizeof(unsigned long long), L.st));
     if (other && other->ev_recorded) PTMI_HIP(ctx, hipStreamWaitEvent(L.st, other->ev_trav, 0));
     if (L.n_ext) launch_render_extend(ctx, pl, sc, ra, pl.q_ext_ray[cur], L.n_ext, L.st);
     uint32_t nsr = 0;
@@ -1142,7 +1189,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     const int bounces = std::max(prm->bounces, 0);
 
     // samples per pixel per batch: bound the per-sample output buffer (<= ~3 GiB, < 2^32/3 samples)
-    uint32_t spp_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp_count, (256ull << 20) / npix));
+    uint32_t spp_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp_count, ((uint64_t)ctx->chunk_msamples << 20) / npix));
     const uint64_t max_total = npix * spp_chunk;
     // two lanes of 2^20 paths when there is enough work to keep both busy, else one
     const int lanes = (ctx->render_lanes >= 2 && max_total >= (1ull << 18)) ? 2 : 1;

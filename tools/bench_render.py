@@ -24,7 +24,7 @@ t0 = time.time(); r = Renderer(sc); print(f"scene {a.scene}: {sc.tris.shape[0]} 
 dev = torch.device("cuda", 0)
 acc = torch.zeros((a.height, a.width, 3), dtype=torch.float32, device=dev); cnt = torch.zeros((a.height, a.width), dtype=torch.int32, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
-r.render_device(acc, cnt, p, sc.camera, spp=1, stream=stream)      # warm-up (allocations)
+r.render_device(acc, cnt, p, sc.camera, spp=a.spp, stream=stream)  # warm-up at full size: the pool and the sample buffer are allocated here
 acc.zero_(); cnt.zero_(); r.bvh.reset_counters(); torch.cuda.synchronize()
 t0 = time.time(); r.render_device(acc, cnt, p, sc.camera, spp=a.spp, stream=stream); torch.cuda.synchronize(); dt = time.time() - t0
 c = r.bvh.counters(); n = a.width * a.height * a.spp
