@@ -194,6 +194,31 @@ def test_tiles_in_one_call(gpu_ctx):
             r.render_tiles_device(a, c, p, sc.camera, bad, spp=1)
 
 
+def test_straggler_hand_over_does_not_change_the_image(monkeypatch):
+    """connect hands a wave's last walking lanes to a second launch (PTMI_CONNECT_BAIL, read when a context is
+    created): off, the default and the maximum give the same sums bit for bit -- an any-hit answer is a pure function of
+    the ray.  (test_many_lights runs the shared last bucket through the retry queue against the oracle.)"""
+    from pathtrace_amd import Context
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    p = make_params(96, 64, bounces=2, seed=9)
+    frames = []
+    for bail in ("0", None, "16"):
+        if bail is None:
+            monkeypatch.delenv("PTMI_CONNECT_BAIL", raising=False)
+        else:
+            monkeypatch.setenv("PTMI_CONNECT_BAIL", bail)
+        ctx = Context(0)
+        try:
+            r = Renderer(sc, ctx=ctx)
+            fb = r.new_framebuffer(96, 64)
+            r.render_tile(fb, p, sc.camera, (0, 0, 96, 64), spp=5)
+            frames.append((fb.accum.copy(), fb.counts.copy()))
+        finally:
+            ctx.close()
+    for a, c in frames[1:]:
+        assert np.array_equal(a, frames[0][0]) and np.array_equal(c, frames[0][1])
+
+
 def test_full_size_frame_properties(gpu_ctx):
     """BASELINE.json configs[2] geometry at full resolution (1920x1080, C3 scene, 16 M-path pool), checked through
     properties: a re-run is bit-identical (queue order and atomics play no part in the sums), two half sample
