@@ -160,21 +160,3 @@ class Renderer:
         check(self._lib.ptmi_to_rgba(self.ctx.handle, _ptr(acc, C.c_float), _ptr(cnt, C.c_uint32), w, h,
                                      _ptr(rgba, C.c_uint8)), self.ctx.handle)
         return rgba
-
-
-def smoke_render(ctx: Context):
-    """Tiny render on the GPU checked against the CPU oracle (used by __graft_entry__.smoke)."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-    import oracle_lib
-    from . import scenes
-    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
-    r = Renderer(sc, ctx=ctx)
-    p = make_params(48, 48, bounces=2, seed=5)
-    got = r.render_samples(p, sc.camera, spp=4)
-    osc = oracle_lib.OracleScene(sc)
-    want = osc.render_samples(sc.camera.as_array(), oracle_lib.OrcParams(48, 48, 2, 1, 1, 0.0, 1000.0, 5), spp_count=4)
-    err = np.abs(got - want) / (1.0 + np.abs(want))
-    assert np.isfinite(got).all() and float(err.max()) < 1e-3, f"render differs from the oracle: max rel err {err.max()}"
-    print(f"smoke render ok: 48x48x4 samples, max rel err vs oracle {err.max():.2e}")

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Any-hit (QuickCheckIntersection) rate on the bench's ray batch, with an oracle check on a strided sample.
-usage: tools/bench_anyhit.py [--tris N] [--rays N]    (PTMI_EXTEND_VARIANT=0 selects the one-shot kernel)"""
+usage: tests/manual/bench_anyhit.py [--tris N] [--rays N]    (PTMI_EXTEND_VARIANT=0 selects the one-shot kernel)"""
 import argparse, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Debug helper: per-configuration mismatch fraction of the GPU integrator against the CPU oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from pathtrace_amd import scenes, Context

@@ -58,3 +58,16 @@ def test_create_without_gpu_reports_no_device():
     with pytest.raises(PtmiError) as e:
         Context(0)
     assert e.value.code == -2
+
+
+def test_product_and_tools_never_load_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline legs may load it."""
+    import glob
+    offenders = []
+    for path in glob.glob(os.path.join(ROOT, "pathtrace_amd", "**", "*"), recursive=True) + glob.glob(os.path.join(ROOT, "tools", "*")):
+        if not os.path.isfile(path) or not path.endswith((".py", ".sh", ".hip", ".cpp", ".hpp", ".h", "Makefile")):
+            continue
+        text = open(path, errors="replace").read()
+        if re.search(r"oracle_lib|liborc|orc_bvh|orc_trace|/oracle\b|\boracle/", text):
+            offenders.append(os.path.relpath(path, ROOT))
+    assert not offenders, offenders
