@@ -491,6 +491,37 @@ def bunny_scene(blob_level=None, glass=False, emissive=False, seed=1, small=Fals
                      lights=np.stack([_sponza_sun()]).astype(F32), sky=_sponza_sky(), camera=cam)
 
 
+def c4_scene(blob_level=9, terrain_n=1600, seed=4):
+    """C4-class scene (BASELINE.json configs[3]: 10 M triangles): a level-9 displaced icosphere (5.2 M triangles) over
+    a 1600 x 1600 height field (5.1 M), a mirror and a glass sphere, an emissive quad; gradient sky + sun as C1/C3.
+    Smaller levels give the same scene for tests."""
+    parts, mats, tri_mat, normals = [], [], [], []
+
+    def add(vf, mat_row, smooth=True):
+        v, f = vf
+        parts.append((v, f))
+        mats.append(mat_row)
+        tri_mat.append(np.full(f.shape[0], len(mats) - 1, dtype=U32))
+        normals.append(corner_normals_smooth(v, f) if smooth else corner_normals_flat(v, f))
+
+    add(displaced_icosphere(blob_level, seed, radius=1.0, amp=0.35, center=(0.0, 1.6, 0.0)), material(kd=(0.75, 0.6, 0.45)))
+    add(terrain(terrain_n, terrain_n, seed + 1, extent=8.0, amp=0.5, y0=0.0), material(kd=(0.5, 0.55, 0.45)))
+    sub = max(1, min(5, blob_level - 3))
+    sv, sf = icosphere(sub)
+    add(((sv * F32(0.6) + np.array([2.1, 1.3, 0.4], dtype=F32)).astype(F32), sf),
+        material(kd=(0.2, 0.2, 0.2), ks=(0.95, 0.95, 0.95), ns=400.0))
+    gv, gf = icosphere(sub)
+    add(((gv * F32(0.55) + np.array([-2.0, 1.3, 0.9], dtype=F32)).astype(F32), gf),
+        material(kd=(0.9, 0.9, 0.9), ni=1.5, flags=MAT_GLASS))
+    add(quad((-1.0, 4.0, -1.0), (1.0, 4.0, -1.0), (1.0, 4.0, 1.0), (-1.0, 4.0, 1.0)),
+        material(kd=(0.0, 0.0, 0.0), ke=(12.0, 11.0, 9.0)), smooth=False)
+    v, f = merge(parts)
+    cam = look_at((3.6, 3.2, 5.6), (0.0, 1.2, 0.0), frustum=2.0)
+    return SceneData(verts=v, tris=f, normals=np.concatenate(normals, 0).astype(F32),
+                     tri_material=np.concatenate(tri_mat).astype(U32), materials=np.stack(mats).astype(F32),
+                     lights=np.stack([_sponza_sun()]).astype(F32), sky=_sponza_sky(), camera=cam)
+
+
 def pack_rgba(rgb):
     """[h,w,3] (or [h,w,4]) uint8 -> packed texels as CacheImage stores them (renderer.go:103-104)."""
     rgb = np.asarray(rgb, dtype=np.uint32)

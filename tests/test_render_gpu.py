@@ -48,6 +48,14 @@ def test_samples_match_oracle(gpu_ctx, glass, emissive, bounces, scatter):
     _compare_samples(sc, p, 4, gpu_ctx)
 
 
+def test_c4_class_scene_matches_oracle(gpu_ctx):
+    """The C4 scene (BASELINE.json configs[3]) at test size: a height field under the blob, a deeper and less balanced
+    tree than the C1/C3 scene's; tools/bench_render.py --scene c4 renders the 10.4 M-triangle version."""
+    sc = scenes.c4_scene(blob_level=4, terrain_n=96)
+    p = make_params(64, 48, bounces=2, seed=17)
+    _compare_samples(sc, p, 3, gpu_ctx)
+
+
 def test_deep_recursion(gpu_ctx):
     """bounces = 7: eight frames per path, the 64-entry tracker history (entries beyond 8 leave the header)."""
     sc = scenes.bunny_scene(small=True, glass=True, emissive=True)

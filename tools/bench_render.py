@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the wavefront integrator on a named scene (samples/s) and optionally dump a PNG.
-usage: tools/bench_render.py [--scene c3|c1|c5] [--width W --height H --spp S] [--png path]"""
+usage: tools/bench_render.py [--scene c3|c1|c4|c5] [--width W --height H --spp S] [--png path]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -15,7 +15,9 @@ ap.add_argument("--height", type=int, default=1080); ap.add_argument("--spp", ty
 ap.add_argument("--bounces", type=int, default=2); ap.add_argument("--png", default=None)
 ap.add_argument("--level", type=int, default=6)
 a = ap.parse_args()
-if a.scene == "c5":
+if a.scene == "c4":
+    sc = scenes.c4_scene(); p = make_params(a.width, a.height, bounces=a.bounces, seed=1)
+elif a.scene == "c5":
     sc = scenes.blackhole_scene(); p = make_params(a.width, a.height, bounces=a.bounces, max_steps=3000, step_size=1.0, seed=1)
 else:
     sc = scenes.bunny_scene(blob_level=a.level, glass=a.scene == "c3", emissive=a.scene == "c3")
