@@ -55,6 +55,7 @@ struct ShadowCounts { uint32_t n[NSB]; };
 // appends to region w % RETRY_SHARDS, at most BAIL_MAX rays, so a region of ceil(waves / RETRY_SHARDS) * BAIL_MAX
 // entries cannot overflow.  The counters follow the queue counters (one memset clears both).
 enum { RETRY_SHARDS = 256, BAIL_MAX = 16 };
+enum { QC_CURSOR = QC_COUNT + RETRY_SHARDS, QC_CURSOR_EXT = QC_CURSOR + 1 };     // ray cursors of the vote-scheduled kernels
 // Path header, 32 words = one 128-byte line per slot (8 x float4):
 //   q0  sample id, RNG key, RNG counter, packed (depth | tracker length << 8 | HP_PENDING)
 //   q1  tracker entry 0, hit status, hit primitive, hit t            (words 1-3 are written by extend)
@@ -316,6 +317,94 @@ __global__ __launch_bounds__(WAVE) void render_connect_retry_kernel(DevBVH bvh, 
     const uint32_t target = f2u(bb.w);
     if (target < pl.cap * (uint32_t)pl.nframes * (uint32_t)pl.nshadow) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = occ ? 1u : 0u;
     else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
+}
+
+// connect, vote-scheduled (the scheduling of connect_vote_kernel, ptmi_api.hip): persistent waves, one step type per
+// iteration chosen by vote, shadow rays dealt in chunks from one cursor over the buckets laid end to end (a chunk is
+// nearly always of one kind), the next ray prefetched while the current one is walked.
+template <int STACK>
+__global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, Pool pl, ShadowCounts sn, unsigned long long *cursor,
+                                                                   unsigned long long *counters, int refill_min, int tri_bias,
+                                                                   uint32_t chunk_rays) {
+    __shared__ uint32_t smem[STACK * WAVE];
+    uint32_t *stack_base = smem + threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+    uint64_t n = 0;
+#pragma unroll
+    for (int k = 0; k < NSB; ++k) n += sn.n[k];
+    const uint32_t ntargets = pl.cap * (uint32_t)pl.nframes * (uint32_t)pl.nshadow;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    TravCounters cnt;
+    RayTrav r;
+    r.cur = D_REF_DONE; r.exact = false; r.sp = 0; r.best = 0; r.best_t = 0.0f;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+    uint32_t my_target = 0, next_target = 0;
+    float nox = 0.f, noy = 0.f, noz = 0.f, ndx = 0.f, ndy = 0.f, ndz = 0.f, ntm = 0.f;
+    bool pending = false, have_next = false;
+    auto grab = [&]() -> unsigned long long {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(cursor, (unsigned long long)chunk_rays);
+        return v;
+    };
+    auto uniform = [&](unsigned long long v) -> uint64_t {
+        return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+               (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    };
+    uint64_t chunk = uniform(grab()), chunk1 = uniform(grab());
+    unsigned long long inflight = grab();
+    uint32_t used = 0;
+    auto reserve = [&](uint32_t k) {
+        const uint64_t idx = k < chunk_rays ? chunk + k : chunk1 + (k - chunk_rays);
+        have_next = idx < n;
+        if (have_next) {
+            uint32_t rem = (uint32_t)idx, b = 0;             // bucket b, entry rem
+#pragma unroll
+            for (int q = 0; q < NSB - 1; ++q) if (b == (uint32_t)q && rem >= sn.n[q]) { rem -= sn.n[q]; b = q + 1; }
+            const size_t e = (size_t)b * pl.cap + rem;
+            const float4 a = pl.q_sray_a[e], bb = pl.q_sray_b[e];
+            nox = a.x; noy = a.y; noz = a.z; ntm = a.w; ndx = bb.x; ndy = bb.y; ndz = bb.z; next_target = f2u(bb.w);
+        }
+    };
+    auto advance = [&](uint32_t taken) {
+        used += taken;
+        if (used >= chunk_rays) { used -= chunk_rays; chunk = chunk1; chunk1 = uniform(inflight); inflight = grab(); }
+    };
+    reserve(lane);
+    advance(WAVE);
+    for (;;) {
+        const bool at_inner = !(r.cur & D_REF_LEAF_BIT);
+        const bool at_tri = (r.cur & D_REF_LEAF_BIT) && r.cur != D_REF_DONE;
+        const bool idle = r.cur == D_REF_DONE;
+        const int nI = __popcll(__ballot(at_inner)), nT = __popcll(__ballot(at_tri));
+        const unsigned long long takers = __ballot(idle && have_next);
+        const int nR = __popcll(takers);
+        if (nI + nT == 0 || nR >= refill_min) {
+            if (idle && pending) {
+                if (my_target < ntargets) ((uint32_t *)pl.sh)[(size_t)my_target * 4 + 3] = r.best ? 1u : 0u;
+                else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
+                pending = false;
+            }
+            if (nR == 0) break;
+            if (idle && have_next) {
+                my_target = next_target; pending = true;
+                trav_init(r, bvh, nox, noy, noz, ndx, ndy, ndz, ntm);
+                r.best = 0;
+                reserve(used + (uint32_t)__popcll(takers & lt_mask));
+            }
+            advance((uint32_t)nR);
+            continue;
+        }
+        if (nI > 0 && (nT == 0 || nI + tri_bias >= nT)) {
+            if (__any(at_inner && r.exact)) {
+                if (at_inner) vote_inner_step_any<WAVE, false, true>(bvh, stack_base, r, cnt);
+            } else {
+                if (at_inner) vote_inner_step_any<WAVE, false, false>(bvh, stack_base, r, cnt);
+            }
+        } else {
+            if (at_tri) vote_tri_step_any<WAVE, false>(bvh, stack_base, r, cnt);
+        }
+    }
+    if (blockIdx.x == 0 && lane == 0 && n) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
 }
 
 // ------------------------------------------------------------------------------------------ shade
@@ -1021,7 +1110,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
         o.qs0 = carve(off, 4 * c); o.qs1 = carve(off, 4 * c);
         o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow);
         o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
-        o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * (QC_COUNT + RETRY_SHARDS) * QC_STRIDE);
+        o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * (QC_COUNT + RETRY_SHARDS + 2) * QC_STRIDE);
         o.retry = carve(off, 4 * retry_shard_cap * RETRY_SHARDS);
     }
     if (hipMalloc((void **)&rs->pool_mem, off) != hipSuccess) {
@@ -1071,6 +1160,20 @@ template <int STACK>
 static void launch_render_connect_t(ptmi_ctx *ctx, const Pool &pl, const ShadowCounts &n, hipStream_t s) {
     unsigned blocks = 0;
     for (int b = 0; b < NSB; ++b) blocks += (n.n[b] + WAVE - 1) / WAVE;
+    if (ctx->connect_vote) {
+        static int per_cu_cached = 0;
+        if (per_cu_cached == 0) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_connect_vote_kernel<STACK>, WAVE, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+            per_cu_cached = per_cu;
+        }
+        const int per_cu = std::min(per_cu_cached, ctx->persist_waves_per_cu);
+        const unsigned pgrid = (unsigned)std::min<uint64_t>(std::max(blocks, 1u), (uint64_t)ctx->num_cus * per_cu);
+        hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n,
+                           pl.qcnt + (size_t)QC_CURSOR * QC_STRIDE, ctx->d_counters, ctx->vote_refill_min, ctx->vote_tri_bias,
+                           (uint32_t)ctx->vote_chunk);
+        return;
+    }
     const int bail = std::max(0, std::min((int)BAIL_MAX, ctx->connect_bail_lanes));
     hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(blocks), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n, ctx->d_counters, bail);
     if (bail > 0) {
@@ -1112,7 +1215,7 @@ static int lane_enqueue(ptmi_ctx *ctx, Lane &L, Lane *other, const DevScene &sc,
     const size_t qc_bytes = (size_t)QC_COUNT * QC_STRIDE * sizeof(unsigned long long);
     auto qc = [&](int which) { return pl.qcnt + (size_t)which * QC_STRIDE; };
     const int cur = L.cur;
-    PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, qc_bytes + (size_t)RETRY_SHARDS * QC_STRIDE * sizeof(unsigned long long), L.st));
+    PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, qc_bytes + (size_t)(RETRY_SHARDS + 2) * QC_STRIDE * sizeof(unsigned long long), L.st));
     if (other && other->ev_recorded) PTMI_HIP(ctx, hipStreamWaitEvent(L.st, other->ev_trav, 0));
     if (L.n_ext) launch_render_extend(ctx, pl, sc, ra, pl.q_ext_ray[cur], L.n_ext, L.st);
     uint32_t nsr = 0;

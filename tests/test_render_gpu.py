@@ -202,19 +202,21 @@ def test_tiles_in_one_call(gpu_ctx):
             r.render_tiles_device(a, c, p, sc.camera, bad, spp=1)
 
 
-def test_straggler_hand_over_does_not_change_the_image(monkeypatch):
-    """connect hands a wave's last walking lanes to a second launch (PTMI_CONNECT_BAIL, read when a context is
-    created): off, the default and the maximum give the same sums bit for bit -- an any-hit answer is a pure function of
-    the ray.  (test_many_lights runs the shared last bucket through the retry queue against the oracle.)"""
+def test_connect_kernels_agree_bit_for_bit(monkeypatch):
+    """connect has two forms, chosen when a context is created: the vote-scheduled persistent kernel (default) and
+    one-shot waves (PTMI_CONNECT_VOTE=0) that hand their last walking lanes to a second launch (PTMI_CONNECT_BAIL lanes,
+    0 = never).  An any-hit answer is a pure function of the ray, so all of them give the same sums bit for bit.
+    (test_many_lights runs the shared last bucket through the default form against the oracle.)"""
     from pathtrace_amd import Context
     sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
     p = make_params(96, 64, bounces=2, seed=9)
     frames = []
-    for bail in ("0", None, "16"):
-        if bail is None:
-            monkeypatch.delenv("PTMI_CONNECT_BAIL", raising=False)
-        else:
-            monkeypatch.setenv("PTMI_CONNECT_BAIL", bail)
+    for vote, bail in ((None, None), ("0", "0"), ("0", None), ("0", "5")):
+        for var, val in (("PTMI_CONNECT_VOTE", vote), ("PTMI_CONNECT_BAIL", bail)):
+            if val is None:
+                monkeypatch.delenv(var, raising=False)
+            else:
+                monkeypatch.setenv(var, val)
         ctx = Context(0)
         try:
             r = Renderer(sc, ctx=ctx)
