@@ -260,6 +260,98 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
     if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)nq);
 }
 
+// extend for straight rays with one segment per call (max_steps == 1, no black hole), vote-scheduled like the batch
+// kernel extend_vote_kernel (ptmi_api.hip): persistent waves, one step type per iteration by vote, queue entries dealt
+// in chunks from one cursor, the next entry prefetched while the current ray is walked.  Same outputs as
+// render_extend_kernel: the hit into the path header, the advanced ray (tracer.go:226-228) back into the entry on a miss.
+template <int STACK>
+__global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Pool pl, RenderArgs ra, float4 *__restrict__ qray,
+                                                                  uint32_t n, unsigned long long *cursor,
+                                                                  unsigned long long *counters, int refill_min, int tri_bias,
+                                                                  uint32_t chunk_rays) {
+    __shared__ uint32_t smem[STACK * WAVE];
+    uint32_t *stack_base = smem + threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const float step = ra.p.step_size;
+    TravCounters cnt;
+    RayTrav r;
+    r.cur = D_REF_DONE; r.exact = false; r.sp = 0; r.best = -1; r.best_t = 0.0f;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+    uint32_t my_entry = 0, next_entry = 0;
+    float my_slot = 0.f, next_slot = 0.f;      // the slot word of the entry, kept as the bits it was read as
+    float nox = 0.f, noy = 0.f, noz = 0.f, ndx = 0.f, ndy = 0.f, ndz = 0.f;
+    bool pending = false, have_next = false;
+    auto grab = [&]() -> unsigned long long {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(cursor, (unsigned long long)chunk_rays);
+        return v;
+    };
+    auto uniform = [&](unsigned long long v) -> uint64_t {
+        return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+               (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    };
+    uint64_t chunk = uniform(grab()), chunk1 = uniform(grab());
+    unsigned long long inflight = grab();
+    uint32_t used = 0;
+    auto reserve = [&](uint32_t k) {
+        const uint64_t idx = k < chunk_rays ? chunk + k : chunk1 + (k - chunk_rays);
+        have_next = idx < n;
+        if (have_next) {
+            next_entry = (uint32_t)idx;
+            const float4 qa = qray[2 * (size_t)idx], qb = qray[2 * (size_t)idx + 1];
+            nox = qa.x; noy = qa.y; noz = qa.z; next_slot = qa.w; ndx = qb.x; ndy = qb.y; ndz = qb.z;
+        }
+    };
+    auto advance = [&](uint32_t taken) {
+        used += taken;
+        if (used >= chunk_rays) { used -= chunk_rays; chunk = chunk1; chunk1 = uniform(inflight); inflight = grab(); }
+    };
+    reserve(lane);
+    advance(WAVE);
+    for (;;) {
+        const bool at_inner = !(r.cur & D_REF_LEAF_BIT);
+        const bool at_tri = (r.cur & D_REF_LEAF_BIT) && r.cur != D_REF_DONE;
+        const bool idle = r.cur == D_REF_DONE;
+        const int nI = __popcll(__ballot(at_inner)), nT = __popcll(__ballot(at_tri));
+        const unsigned long long takers = __ballot(idle && have_next);
+        const int nR = __popcll(takers);
+        if (nI + nT == 0 || nR >= refill_min) {
+            if (idle && pending) {
+                uint32_t slot = f2u(my_slot);
+                if (slot >= pl.cap) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT); slot = 0; }
+                float *h1 = (float *)(pl.hdr + (size_t)slot * HQ + 1);                 // word 0 (tracker entry 0) is shade's
+                const bool hit = r.best >= 0;
+                h1[1] = i2f(hit ? HS_HIT : HS_MISS); h1[2] = i2f(r.best); h1[3] = hit ? r.best_t : 0.0f;
+                if (!hit) {                                                            // :226-228, as render_extend_kernel
+                    const V3 o = add(mk(r.ox, r.oy, r.oz), scale(mk(r.dx, r.dy, r.dz), step));
+                    qray[2 * (size_t)my_entry] = make_float4(o.x, o.y, o.z, my_slot);
+                    qray[2 * (size_t)my_entry + 1] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+                }
+                pending = false;
+            }
+            if (nR == 0) break;
+            if (idle && have_next) {
+                my_entry = next_entry; my_slot = next_slot; pending = true;
+                trav_init(r, bvh, nox, noy, noz, ndx, ndy, ndz, step);
+                reserve(used + (uint32_t)__popcll(takers & lt_mask));
+            }
+            advance((uint32_t)nR);
+            continue;
+        }
+        if (nI > 0 && (nT == 0 || nI + tri_bias >= nT)) {
+            if (__any(at_inner && r.exact)) {
+                if (at_inner) vote_inner_step<WAVE, false, true>(bvh, stack_base, r, cnt);
+            } else {
+                if (at_inner) vote_inner_step<WAVE, false, false>(bvh, stack_base, r, cnt);
+            }
+        } else {
+            if (at_tri) vote_tri_step<WAVE, false>(bvh, stack_base, r, cnt);
+        }
+    }
+    if (blockIdx.x == 0 && lane == 0 && n) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)n);
+}
+
 // ------------------------------------------------------------------------------------------ connect
 // Bucket b's rays sit at q_sray[b * cap ...]; workgroups are dealt to the buckets in order.
 template <int STACK>
@@ -1140,6 +1232,23 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
 template <int STACK>
 static void launch_render_extend_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, float4 *qray,
                                    uint32_t n, hipStream_t s) {
+    // one-shot waves win while the tree is cache resident (C3, 85 k triangles: +2 %), the vote-scheduled kernel beyond
+    // (1.3 M triangles: +1.6 %, 10.4 M: +9 %); PTMI_EXTEND_VOTE=0/1 forces one or the other
+    const bool vote = ctx->extend_vote < 0 ? sc.ntris >= (1u << 20) : ctx->extend_vote != 0;
+    if (!sc.has_bh && ra.p.max_steps == 1 && vote) {
+        static int per_cu_cached = 0;
+        if (per_cu_cached == 0) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_extend_vote_kernel<STACK>, WAVE, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+            per_cu_cached = per_cu;
+        }
+        const int per_cu = std::min(per_cu_cached, ctx->persist_waves_per_cu);
+        const unsigned pgrid = (unsigned)std::min<uint64_t>((n + WAVE - 1) / WAVE, (uint64_t)ctx->num_cus * per_cu);
+        hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, qray, n,
+                           pl.qcnt + (size_t)QC_CURSOR_EXT * QC_STRIDE, ctx->d_counters, ctx->vote_refill_min, ctx->vote_tri_bias,
+                           (uint32_t)ctx->vote_chunk);
+        return;
+    }
     if (sc.has_bh)
         hipLaunchKernelGGL((render_extend_kernel<STACK, true>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
                            pl, sc, ra, qray, n, ctx->d_counters);

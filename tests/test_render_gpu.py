@@ -202,17 +202,18 @@ def test_tiles_in_one_call(gpu_ctx):
             r.render_tiles_device(a, c, p, sc.camera, bad, spp=1)
 
 
-def test_connect_kernels_agree_bit_for_bit(monkeypatch):
+def test_traversal_kernel_forms_agree_bit_for_bit(monkeypatch):
     """connect has two forms, chosen when a context is created: the vote-scheduled persistent kernel (default) and
     one-shot waves (PTMI_CONNECT_VOTE=0) that hand their last walking lanes to a second launch (PTMI_CONNECT_BAIL lanes,
-    0 = never).  An any-hit answer is a pure function of the ray, so all of them give the same sums bit for bit.
+    0 = never); extend has a vote-scheduled form too (PTMI_EXTEND_VOTE, by default chosen by tree size).  The answer of
+    a walk is a pure function of the ray, so all of them give the same sums bit for bit.
     (test_many_lights runs the shared last bucket through the default form against the oracle.)"""
     from pathtrace_amd import Context
     sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
     p = make_params(96, 64, bounces=2, seed=9)
     frames = []
-    for vote, bail in ((None, None), ("0", "0"), ("0", None), ("0", "5")):
-        for var, val in (("PTMI_CONNECT_VOTE", vote), ("PTMI_CONNECT_BAIL", bail)):
+    for vote, bail, ext in ((None, None, None), ("0", "0", "0"), ("0", None, "1"), ("0", "5", None), (None, None, "1")):
+        for var, val in (("PTMI_CONNECT_VOTE", vote), ("PTMI_CONNECT_BAIL", bail), ("PTMI_EXTEND_VOTE", ext)):
             if val is None:
                 monkeypatch.delenv(var, raising=False)
             else:
