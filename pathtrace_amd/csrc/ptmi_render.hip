@@ -1246,7 +1246,7 @@ static void launch_render_extend_t(ptmi_ctx *ctx, const Pool &pl, const DevScene
         const unsigned pgrid = (unsigned)std::min<uint64_t>((n + WAVE - 1) / WAVE, (uint64_t)ctx->num_cus * per_cu);
         hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, qray, n,
                            pl.qcnt + (size_t)QC_CURSOR_EXT * QC_STRIDE, ctx->d_counters, ctx->vote_refill_min, ctx->vote_tri_bias,
-                           (uint32_t)ctx->vote_chunk);
+                           (uint32_t)ctx->render_vote_chunk);
         return;
     }
     if (sc.has_bh)
@@ -1280,7 +1280,7 @@ static void launch_render_connect_t(ptmi_ctx *ctx, const Pool &pl, const ShadowC
         const unsigned pgrid = (unsigned)std::min<uint64_t>(std::max(blocks, 1u), (uint64_t)ctx->num_cus * per_cu);
         hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n,
                            pl.qcnt + (size_t)QC_CURSOR * QC_STRIDE, ctx->d_counters, ctx->vote_refill_min, ctx->vote_tri_bias,
-                           (uint32_t)ctx->vote_chunk);
+                           (uint32_t)ctx->render_vote_chunk);
         return;
     }
     const int bail = std::max(0, std::min((int)BAIL_MAX, ctx->connect_bail_lanes));
