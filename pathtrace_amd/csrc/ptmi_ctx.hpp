@@ -60,7 +60,7 @@ struct ptmi_ctx {
     int pool_paths = 1 << 25;           // most paths in flight in the integrator's pool ...
     uint64_t pool_bytes_max = 96ull << 30;   // ... and most device memory the pool may take
     int chunk_msamples = 256;           // samples per pass over the region, in 2^20 (bounds the per-sample output buffer: 12 B each)
-    int extend_vote = -1;               // extend (straight rays, one segment per call) as a vote-scheduled persistent kernel: -1 = by tree size
+    int extend_vote = 1;                // extend (straight rays, one segment per call) as a vote-scheduled persistent kernel (0: one-shot)
     int render_vote_chunk = 256;        // queue entries reserved per cursor atomic in the integrator's vote-scheduled kernels
     int connect_vote = 1;               // connect as a vote-scheduled persistent kernel (0: one-shot waves + hand-over)
     int connect_bail_lanes = 16;        // connect: a wave hands its last N walking lanes to a second launch (0 = off)

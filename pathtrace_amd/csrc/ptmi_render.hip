@@ -1232,10 +1232,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
 template <int STACK>
 static void launch_render_extend_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, float4 *qray,
                                    uint32_t n, hipStream_t s) {
-    // one-shot waves win while the tree is cache resident (C3, 85 k triangles: +2 %), the vote-scheduled kernel beyond
-    // (1.3 M triangles: +1.6 %, 10.4 M: +9 %); PTMI_EXTEND_VOTE=0/1 forces one or the other
-    const bool vote = ctx->extend_vote < 0 ? sc.ntris >= (1u << 20) : ctx->extend_vote != 0;
-    if (!sc.has_bh && ra.p.max_steps == 1 && vote) {
+    if (!sc.has_bh && ra.p.max_steps == 1 && ctx->extend_vote) {
         static int per_cu_cached = 0;
         if (per_cu_cached == 0) {
             int per_cu = 0;
