@@ -367,6 +367,7 @@ extern "C" int ptmi_create(int device, ptmi_ctx **out) {
         if (const char *v = getenv("PTMI_RENDER_LANES")) ctx->render_lanes = atoi(v);
         if (const char *v = getenv("PTMI_CONNECT_BAIL")) ctx->connect_bail_lanes = atoi(v);
         if (const char *v = getenv("PTMI_CONNECT_VOTE")) ctx->connect_vote = atoi(v);
+        if (const char *v = getenv("PTMI_SEGMENT_SHORTCUT")) ctx->segment_shortcut = atoi(v);
         if (const char *v = getenv("PTMI_RENDER_VOTE_CHUNK")) ctx->render_vote_chunk = std::max(64, atoi(v) / 64 * 64);
         if (const char *v = getenv("PTMI_EXTEND_VOTE")) ctx->extend_vote = atoi(v);
         if (const char *v = getenv("PTMI_CHUNK_MSAMPLES")) ctx->chunk_msamples = std::max(1, std::min(1024, atoi(v)));
@@ -421,6 +422,23 @@ static int upload_packed(ptmi_ctx *ctx, const float *verts, uint64_t nverts, con
     ctx->root_ref = packed.root_ref;
     ctx->bounds_finite = packed.bounds_finite ? 1u : 0u;
     ctx->dummy_tri = packed.dummy_tri;
+    {   // tight box: union of the non-empty child boxes (an inverted box holds no triangle)
+        float lo[3] = {PT_INF, PT_INF, PT_INF}, hi[3] = {-PT_INF, -PT_INF, -PT_INF};
+        bool any = false;
+        for (const PackedNode &pn : packed.nodes) {
+            const float *ax[3] = {pn.x, pn.y, pn.z};
+            for (int c = 0; c < 2; ++c) {
+                if (!(ax[0][2 * c] <= ax[0][2 * c + 1] && ax[1][2 * c] <= ax[1][2 * c + 1] && ax[2][2 * c] <= ax[2][2 * c + 1])) continue;
+                for (int x = 0; x < 3; ++x) { lo[x] = std::min(lo[x], ax[x][2 * c]); hi[x] = std::max(hi[x], ax[x][2 * c + 1]); }
+                any = true;
+            }
+        }
+        float mag = 0.0f;
+        for (int x = 0; x < 3; ++x) { ctx->tight_min[x] = lo[x]; ctx->tight_max[x] = hi[x]; mag = std::max(mag, std::max(std::fabs(lo[x]), std::fabs(hi[x]))); }
+        // rounding of (bound - o) * inv against `step`: a few ulps of max(|bound|, |o|) <= 1e5 -> < 0.05; plus 1e-3 relative
+        ctx->tight_margin = 0.1f + 1e-3f * mag;
+        ctx->tight_valid = (ctx->segment_shortcut && any && packed.bounds_finite && !(packed.root_ref & D_REF_LEAF_BIT) && mag <= SEG_OUTSIDE_MAX_ORIGIN) ? 1u : 0u;
+    }
     ctx->max_depth = packed.max_depth;
     ctx->packed_inner = packed.nodes.size();
     ctx->packed_tris = packed.tris.size();

@@ -62,6 +62,7 @@ struct ptmi_ctx {
     int chunk_msamples = 256;           // samples per pass over the region, in 2^20 (bounds the per-sample output buffer: 12 B each)
     int extend_vote = 1;                // extend (straight rays, one segment per call) as a vote-scheduled persistent kernel (0: one-shot)
     int render_vote_chunk = 256;        // queue entries reserved per cursor atomic in the integrator's vote-scheduled kernels
+    int segment_shortcut = 1;           // the curved march skips the walk for segments far outside the tree's tight box
     int connect_vote = 1;               // connect as a vote-scheduled persistent kernel (0: one-shot waves + hand-over)
     int connect_bail_lanes = 16;        // connect: a wave hands its last N walking lanes to a second launch (0 = off)
     int render_lanes = 1;               // path pools worked side by side (2 = pipelined lanes: measured 7 % slower, shade fills the VGPR file)
@@ -73,7 +74,12 @@ struct ptmi_ctx {
     bool counting = false;
     unsigned long long *d_counters = nullptr;
 
-    ptmi::DevBVH dev_bvh() const { return ptmi::DevBVH{d_nodes, d_tris, root_ref, bounds_finite, dummy_tri}; }
+    float tight_min[3] = {0, 0, 0}, tight_max[3] = {0, 0, 0}, tight_margin = 0.0f;   // see DevBVH
+    uint32_t tight_valid = 0;
+    ptmi::DevBVH dev_bvh() const {
+        return ptmi::DevBVH{d_nodes, d_tris, root_ref, bounds_finite, dummy_tri,
+                            {tight_min[0], tight_min[1], tight_min[2]}, {tight_max[0], tight_max[1], tight_max[2]}, tight_margin, tight_valid};
+    }
 };
 
 namespace ptmi {

@@ -235,7 +235,9 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
         TravCounters tc;
         for (int step = 0; step < ra.p.max_steps; ++step) {
             ++nq;
-            closest_hit<WAVE, false>(bvh, smem + threadIdx.x, o.x, o.y, o.z, d.x, d.y, d.z, ra.p.step_size, prim, t, tc);
+            // a geodesic spends most of its 3 000 segments far from any geometry: those queries are misses without a walk
+            if (CURVED && segment_outside_tree(bvh, o.x, o.y, o.z, d.x, d.y, d.z, ra.p.step_size)) { prim = -1; t = 0.0f; }
+            else closest_hit<WAVE, false>(bvh, smem + threadIdx.x, o.x, o.y, o.z, d.x, d.y, d.z, ra.p.step_size, prim, t, tc);
             if (prim >= 0) { status = HS_HIT; break; }
             moved = true;
             if (!CURVED) {

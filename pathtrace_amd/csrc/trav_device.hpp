@@ -21,7 +21,29 @@ struct DevBVH {
     uint32_t root_ref;
     uint32_t bounds_finite;   // every child box of every packed node is finite (enables slab_fast)
     uint32_t dummy_tri;       // record empty leaves point at (degenerate, never hit); only the counters care
+    // union of the non-empty child boxes of all packed nodes (every leaf that holds a triangle lies inside) and a
+    // margin that covers the rounding of the slab test for origins up to SEG_OUTSIDE_MAX_ORIGIN; 0 = not usable
+    float tight_min[3], tight_max[3], tight_margin;
+    uint32_t tight_valid;
 };
+constexpr float SEG_OUTSIDE_MAX_ORIGIN = 1.0e5f;
+
+// True when the segment [o, o + d*step] (|d| <= ~1) lies outside the tree's tight box by more than the margin on some
+// axis.  Then the slab test (linear_bvh.go:23-70) fails for every box inside the tight box -- on that axis both plane
+// distances are negative, or both exceed `step` by far more than their rounding -- so the reference's walk pops the
+// root's two children and ends without testing a triangle: the query is a miss, and the walk can be skipped.
+__device__ __forceinline__ bool segment_outside_tree(const DevBVH &bvh, float ox, float oy, float oz, float dx, float dy,
+                                                     float dz, float step) {
+    if (!bvh.tight_valid) return false;
+    const float ex = ox + dx * step, ey = oy + dy * step, ez = oz + dz * step;
+    const float m = bvh.tight_margin;
+    const bool ok = fabsf(ox) <= SEG_OUTSIDE_MAX_ORIGIN && fabsf(oy) <= SEG_OUTSIDE_MAX_ORIGIN && fabsf(oz) <= SEG_OUTSIDE_MAX_ORIGIN &&
+                    fabsf(ex) <= SEG_OUTSIDE_MAX_ORIGIN && fabsf(ey) <= SEG_OUTSIDE_MAX_ORIGIN && fabsf(ez) <= SEG_OUTSIDE_MAX_ORIGIN;
+    const bool out = fminf(ox, ex) > bvh.tight_max[0] + m || fmaxf(ox, ex) < bvh.tight_min[0] - m ||
+                     fminf(oy, ey) > bvh.tight_max[1] + m || fmaxf(oy, ey) < bvh.tight_min[1] - m ||
+                     fminf(oz, ez) > bvh.tight_max[2] + m || fmaxf(oz, ez) < bvh.tight_min[2] - m;
+    return ok && out;          // a NaN anywhere makes `ok` or `out` false: the walk runs
+}
 
 
 // Packed node quarters: q0 = c0min.x c0max.x c1min.x c1max.x | q1 = same for y | q2 = same for z |

@@ -292,6 +292,29 @@ def test_blackhole_scene(gpu_ctx):
     assert (want.sum(-1) > 0).mean() > 0.02     # the disk is visible
 
 
+def test_march_shortcut_does_not_change_the_image(monkeypatch):
+    """The curved march answers "miss" without a walk for a segment that lies outside the tight box of the tree by
+    more than a margin (segment_outside_tree): the reference's slab tests fail for every such segment, so the frame
+    with and without the shortcut is the same bit for bit.  The camera looks along the disk plane, so that geodesics
+    graze the box."""
+    from pathtrace_amd import Context
+    sc = scenes.blackhole_scene(segments=96)
+    p = make_params(48, 40, bounces=1, max_steps=3000, step_size=1.0, seed=4)
+    cams = [sc.camera, scenes.look_at((1500.0, 3.0, 0.0), (0.0, 0.0, 0.0), frustum=2.0)]
+    frames = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("PTMI_SEGMENT_SHORTCUT", on)
+        ctx = Context(0)
+        try:
+            r = Renderer(sc, ctx=ctx)
+            frames.append([r.render_samples(p, cam, spp=1) for cam in cams])
+        finally:
+            ctx.close()
+    for a, b in zip(*frames):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert (frames[0][1].sum(-1) > 0).any()
+
+
 def test_render_errors(gpu_ctx):
     from pathtrace_amd import PtmiError, Context
     sc = scenes.bunny_scene(small=True)
