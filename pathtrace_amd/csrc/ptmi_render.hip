@@ -1231,6 +1231,20 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     return PTMI_OK;
 }
 
+// A persistent wave of the vote-scheduled kernels reserves three chunks of queue entries before it starts (one in use,
+// two ahead), so a launch needs at least 3 * 64 rays per resident wave for every wave to get work at all, and measured
+// (tools/ab_env_tiles.sh) the one-shot kernels stay ahead up to about eight times that: 10 M rays on this chip.  Below
+// the bound the one-shot kernels run (the draining iterations at the end of a call, tiles rendered one per call),
+// above it the vote-scheduled ones with chunks of render_vote_chunk entries.  Returns 0 for "one-shot".
+// PTMI_RENDER_VOTE_MIN overrides the bound (tests force the vote-scheduled kernels at small sizes with 0).
+static uint32_t vote_chunk_for(const ptmi_ctx *ctx, uint64_t nrays, int per_cu) {
+    const uint64_t waves = (uint64_t)ctx->num_cus * (uint64_t)per_cu;
+    const uint64_t least = ctx->render_vote_min >= 0 ? (uint64_t)ctx->render_vote_min : waves * 3 * WAVE * 8;
+    if (nrays < least || nrays == 0) return 0;
+    const uint64_t fair = nrays / (3 * waves) / WAVE * WAVE;
+    return (uint32_t)std::min<uint64_t>((uint64_t)ctx->render_vote_chunk, std::max<uint64_t>(WAVE, fair));
+}
+
 template <int STACK>
 static void launch_render_extend_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, float4 *qray,
                                    uint32_t n, hipStream_t s) {
@@ -1242,11 +1256,14 @@ static void launch_render_extend_t(ptmi_ctx *ctx, const Pool &pl, const DevScene
             per_cu_cached = per_cu;
         }
         const int per_cu = std::min(per_cu_cached, ctx->persist_waves_per_cu);
-        const unsigned pgrid = (unsigned)std::min<uint64_t>((n + WAVE - 1) / WAVE, (uint64_t)ctx->num_cus * per_cu);
-        hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, qray, n,
-                           pl.qcnt + (size_t)QC_CURSOR_EXT * QC_STRIDE, ctx->d_counters, ctx->vote_refill_min, ctx->vote_tri_bias,
-                           (uint32_t)ctx->render_vote_chunk);
-        return;
+        const uint32_t chunk = vote_chunk_for(ctx, n, per_cu);
+        if (chunk) {
+            const unsigned pgrid = (unsigned)std::min<uint64_t>((n + WAVE - 1) / WAVE, (uint64_t)ctx->num_cus * per_cu);
+            hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, qray, n,
+                               pl.qcnt + (size_t)QC_CURSOR_EXT * QC_STRIDE, ctx->d_counters, ctx->vote_refill_min,
+                               ctx->vote_tri_bias, chunk);
+            return;
+        }
     }
     if (sc.has_bh)
         hipLaunchKernelGGL((render_extend_kernel<STACK, true>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
@@ -1276,11 +1293,16 @@ static void launch_render_connect_t(ptmi_ctx *ctx, const Pool &pl, const ShadowC
             per_cu_cached = per_cu;
         }
         const int per_cu = std::min(per_cu_cached, ctx->persist_waves_per_cu);
-        const unsigned pgrid = (unsigned)std::min<uint64_t>(std::max(blocks, 1u), (uint64_t)ctx->num_cus * per_cu);
-        hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n,
-                           pl.qcnt + (size_t)QC_CURSOR * QC_STRIDE, ctx->d_counters, ctx->vote_refill_min, ctx->vote_tri_bias,
-                           (uint32_t)ctx->render_vote_chunk);
-        return;
+        uint64_t nrays = 0;
+        for (int b = 0; b < NSB; ++b) nrays += n.n[b];
+        const uint32_t chunk = vote_chunk_for(ctx, nrays, per_cu);
+        if (chunk) {
+            const unsigned pgrid = (unsigned)std::min<uint64_t>(std::max(blocks, 1u), (uint64_t)ctx->num_cus * per_cu);
+            hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n,
+                               pl.qcnt + (size_t)QC_CURSOR * QC_STRIDE, ctx->d_counters, ctx->vote_refill_min, ctx->vote_tri_bias,
+                               chunk);
+            return;
+        }
     }
     const int bail = std::max(0, std::min((int)BAIL_MAX, ctx->connect_bail_lanes));
     hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(blocks), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n, ctx->d_counters, bail);

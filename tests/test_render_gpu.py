@@ -212,8 +212,11 @@ def test_traversal_kernel_forms_agree_bit_for_bit(monkeypatch):
     sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
     p = make_params(96, 64, bounces=2, seed=9)
     frames = []
-    for vote, bail, ext in ((None, None, None), ("0", "0", "0"), ("0", None, "1"), ("0", "5", None), (None, None, "1")):
-        for var, val in (("PTMI_CONNECT_VOTE", vote), ("PTMI_CONNECT_BAIL", bail), ("PTMI_EXTEND_VOTE", ext)):
+    # launches this small run the one-shot kernels unless PTMI_RENDER_VOTE_MIN=0 forces the vote-scheduled ones
+    for vote, bail, ext, vmin in ((None, None, None, "0"), ("0", "0", "0", "0"), ("0", None, "1", "0"), ("0", "5", None, "0"),
+                                  (None, None, None, None), ("1", "0", "1", "0")):
+        for var, val in (("PTMI_CONNECT_VOTE", vote), ("PTMI_CONNECT_BAIL", bail), ("PTMI_EXTEND_VOTE", ext),
+                         ("PTMI_RENDER_VOTE_MIN", vmin)):
             if val is None:
                 monkeypatch.delenv(var, raising=False)
             else:
