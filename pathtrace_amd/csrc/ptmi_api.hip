@@ -74,17 +74,7 @@ __global__ __launch_bounds__(WAVE) void extend_kernel(DevBVH bvh, const float *_
     flush_counters<COUNT>(cnt, counters, CNT_CLOSEST, live ? 1u : 0u);
 }
 
-// The production extend kernel: persistent waves, vote-scheduled single steps.  Every iteration the wave counts its lanes at
-// an inner node (I), at a triangle record (T) and idle with a ray in reserve (R), and runs ONE step type for
-// the lanes in that state: refill when enough lanes are idle (or nothing else is left), otherwise the
-// majority of I / T.  A waiting state's population only grows until it is served, so no lane starves.
-//
-// Rays are dealt in 64-ray chunks from one global cursor, in batch order: at any moment the whole chip works
-// on neighbouring rays, which keeps the touched part of the tree in L2 (dealing chunks statically per wave
-// was measured 25 % slower for that reason).  The cursor is only touched once per chunk and two chunks ahead
-// of use, and each lane keeps its NEXT ray prefetched in registers, loaded while the current one is
-// traversed, so neither the atomic nor the ray fetch is ever waited for.  The loop ends when the cursor has
-// passed n and every lane has drained and stored its result.
+// The production extend kernel: persistent waves walking vote-scheduled single steps (vote_walk, trav_device.hpp).
 template <int STACK, bool COUNT>
 __global__ __launch_bounds__(WAVE) void extend_vote_kernel(DevBVH bvh, const float *__restrict__ o,
                                                            const float *__restrict__ d,
@@ -94,84 +84,16 @@ __global__ __launch_bounds__(WAVE) void extend_vote_kernel(DevBVH bvh, const flo
                                                            unsigned long long *cursor, int refill_min, int tri_bias,
                                                            uint32_t chunk_rays) {
     __shared__ uint32_t smem[STACK * WAVE];
-    uint32_t *stack_base = smem + threadIdx.x;
-    const uint32_t lane = threadIdx.x;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     TravCounters cnt;
-    RayTrav r;
-    r.cur = D_REF_DONE; r.exact = false; r.sp = 0; r.best = -1; r.best_t = 0.0f;
-    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
-    uint64_t my_ray = 0, next_ray = 0;
-    float nox = 0.f, noy = 0.f, noz = 0.f, ndx = 0.f, ndy = 0.f, ndz = 0.f, ntm = 0.f;
-    bool pending = false, have_next = false;
-    uint32_t nrays = 0;
-    // chunk pipeline (wave-uniform): `chunk` is being handed out, `chunk1` is ready, `inflight` (lane 0) is on its way
-    auto grab = [&]() -> unsigned long long {
-        unsigned long long v = 0;
-        if (lane == 0) v = atomicAdd(cursor, (unsigned long long)chunk_rays);
-        return v;
-    };
-    auto uniform = [&](unsigned long long v) -> uint64_t {
-        return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
-               (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
-    };
-    uint64_t chunk = uniform(grab()), chunk1 = uniform(grab());
-    unsigned long long inflight = grab();
-    uint32_t used = 0;                      // rays of `chunk` already reserved
-    auto reserve = [&](uint32_t k) {        // k-th ray counted from the start of `chunk` -> prefetch registers
-        const uint64_t idx = k < chunk_rays ? chunk + k : chunk1 + (k - chunk_rays);
-        have_next = idx < n;
-        if (have_next) {
-            next_ray = idx;
-            nox = o[3 * idx]; noy = o[3 * idx + 1]; noz = o[3 * idx + 2];
-            ndx = d[3 * idx]; ndy = d[3 * idx + 1]; ndz = d[3 * idx + 2];
-            ntm = tmax[idx];
-        }
-    };
-    auto advance = [&](uint32_t taken) {
-        used += taken;
-        if (used >= chunk_rays) {
-            used -= chunk_rays;
-            chunk = chunk1;
-            chunk1 = uniform(inflight);
-            inflight = grab();
-        }
-    };
-    reserve(lane);
-    advance(WAVE);
-    for (;;) {
-        const bool at_inner = !(r.cur & D_REF_LEAF_BIT);
-        const bool at_tri = (r.cur & D_REF_LEAF_BIT) && r.cur != D_REF_DONE;
-        const bool idle = r.cur == D_REF_DONE;
-        const int nI = __popcll(__ballot(at_inner)), nT = __popcll(__ballot(at_tri));
-        const unsigned long long takers = __ballot(idle && have_next);
-        const int nR = __popcll(takers);
-        if (nI + nT == 0 || nR >= refill_min) {
-            // ---- R step: store finished results, start the prefetched rays, reserve the next ones ----
-            if (idle && pending) {
-                prim[my_ray] = r.best;
-                t[my_ray] = r.best >= 0 ? r.best_t : 0.0f;
-                pending = false;
-            }
-            if (nR == 0) break;             // nothing left to start, nothing in flight: the wave is done
-            if (idle && have_next) {
-                my_ray = next_ray; pending = true; ++nrays;
-                trav_init(r, bvh, nox, noy, noz, ndx, ndy, ndz, ntm);
-                reserve(used + (uint32_t)__popcll(takers & lt_mask));
-            }
-            advance((uint32_t)nR);
-            continue;
-        }
-        if (nI > 0 && (nT == 0 || nI + tri_bias >= nT)) {
-            if (__any(at_inner && r.exact)) {
-                if (at_inner) vote_inner_step<WAVE, COUNT, true>(bvh, stack_base, r, cnt);
-            } else {
-                if (at_inner) vote_inner_step<WAVE, COUNT, false>(bvh, stack_base, r, cnt);
-            }
-        } else {
-            if (at_tri) vote_tri_step<WAVE, COUNT>(bvh, stack_base, r, cnt);
-        }
-    }
+    const uint32_t nrays = vote_walk<WAVE, false, COUNT, uint64_t>(
+        bvh, smem + threadIdx.x, n, cursor, refill_min, tri_bias, chunk_rays, cnt,
+        [&](uint64_t idx, NextRay &nx, uint64_t &tag) {
+            tag = idx;
+            nx.ox = o[3 * idx]; nx.oy = o[3 * idx + 1]; nx.oz = o[3 * idx + 2];
+            nx.dx = d[3 * idx]; nx.dy = d[3 * idx + 1]; nx.dz = d[3 * idx + 2];
+            nx.tmax = tmax[idx];
+        },
+        [&](uint64_t ray, const RayTrav &r) { prim[ray] = r.best; t[ray] = r.best >= 0 ? r.best_t : 0.0f; });
     flush_counters<COUNT>(cnt, counters, CNT_CLOSEST, nrays);
 }
 
@@ -192,8 +114,7 @@ __global__ __launch_bounds__(WAVE) void connect_kernel(DevBVH bvh, const float *
     flush_counters<COUNT>(cnt, counters, CNT_ANY, live ? 1u : 0u);
 }
 
-// The any-hit batch kernel, scheduled like extend_vote_kernel (persistent waves, one step type per iteration by
-// vote, rays dealt from one cursor in chunks, next ray prefetched).  Every ray walks its nodes in the order of
+// The any-hit batch kernel, scheduled like extend_vote_kernel.  Every ray walks its nodes in the order of
 // QuickCheckIntersection, so the work counters equal the reference walk's.
 template <int STACK, bool COUNT>
 __global__ __launch_bounds__(WAVE) void connect_vote_kernel(DevBVH bvh, const float *__restrict__ o,
@@ -203,79 +124,16 @@ __global__ __launch_bounds__(WAVE) void connect_vote_kernel(DevBVH bvh, const fl
                                                             unsigned long long *counters, unsigned long long *cursor,
                                                             int refill_min, int tri_bias, uint32_t chunk_rays) {
     __shared__ uint32_t smem[STACK * WAVE];
-    uint32_t *stack_base = smem + threadIdx.x;
-    const uint32_t lane = threadIdx.x;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     TravCounters cnt;
-    RayTrav r;
-    r.cur = D_REF_DONE; r.exact = false; r.sp = 0; r.best = 0; r.best_t = 0.0f;
-    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
-    uint64_t my_ray = 0, next_ray = 0;
-    float nox = 0.f, noy = 0.f, noz = 0.f, ndx = 0.f, ndy = 0.f, ndz = 0.f, ntm = 0.f;
-    bool pending = false, have_next = false;
-    uint32_t nrays = 0;
-    auto grab = [&]() -> unsigned long long {
-        unsigned long long v = 0;
-        if (lane == 0) v = atomicAdd(cursor, (unsigned long long)chunk_rays);
-        return v;
-    };
-    auto uniform = [&](unsigned long long v) -> uint64_t {
-        return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
-               (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
-    };
-    uint64_t chunk = uniform(grab()), chunk1 = uniform(grab());
-    unsigned long long inflight = grab();
-    uint32_t used = 0;
-    auto reserve = [&](uint32_t k) {
-        const uint64_t idx = k < chunk_rays ? chunk + k : chunk1 + (k - chunk_rays);
-        have_next = idx < n;
-        if (have_next) {
-            next_ray = idx;
-            nox = o[3 * idx]; noy = o[3 * idx + 1]; noz = o[3 * idx + 2];
-            ndx = d[3 * idx]; ndy = d[3 * idx + 1]; ndz = d[3 * idx + 2];
-            ntm = tmax[idx];
-        }
-    };
-    auto advance = [&](uint32_t taken) {
-        used += taken;
-        if (used >= chunk_rays) {
-            used -= chunk_rays;
-            chunk = chunk1;
-            chunk1 = uniform(inflight);
-            inflight = grab();
-        }
-    };
-    reserve(lane);
-    advance(WAVE);
-    for (;;) {
-        const bool at_inner = !(r.cur & D_REF_LEAF_BIT);
-        const bool at_tri = (r.cur & D_REF_LEAF_BIT) && r.cur != D_REF_DONE;
-        const bool idle = r.cur == D_REF_DONE;
-        const int nI = __popcll(__ballot(at_inner)), nT = __popcll(__ballot(at_tri));
-        const unsigned long long takers = __ballot(idle && have_next);
-        const int nR = __popcll(takers);
-        if (nI + nT == 0 || nR >= refill_min) {
-            if (idle && pending) { occluded[my_ray] = r.best ? 1 : 0; pending = false; }
-            if (nR == 0) break;
-            if (idle && have_next) {
-                my_ray = next_ray; pending = true; ++nrays;
-                trav_init(r, bvh, nox, noy, noz, ndx, ndy, ndz, ntm);
-                r.best = 0;
-                reserve(used + (uint32_t)__popcll(takers & lt_mask));
-            }
-            advance((uint32_t)nR);
-            continue;
-        }
-        if (nI > 0 && (nT == 0 || nI + tri_bias >= nT)) {
-            if (__any(at_inner && r.exact)) {
-                if (at_inner) vote_inner_step_any<WAVE, COUNT, true>(bvh, stack_base, r, cnt);
-            } else {
-                if (at_inner) vote_inner_step_any<WAVE, COUNT, false>(bvh, stack_base, r, cnt);
-            }
-        } else {
-            if (at_tri) vote_tri_step_any<WAVE, COUNT>(bvh, stack_base, r, cnt);
-        }
-    }
+    const uint32_t nrays = vote_walk<WAVE, true, COUNT, uint64_t>(
+        bvh, smem + threadIdx.x, n, cursor, refill_min, tri_bias, chunk_rays, cnt,
+        [&](uint64_t idx, NextRay &nx, uint64_t &tag) {
+            tag = idx;
+            nx.ox = o[3 * idx]; nx.oy = o[3 * idx + 1]; nx.oz = o[3 * idx + 2];
+            nx.dx = d[3 * idx]; nx.dy = d[3 * idx + 1]; nx.dz = d[3 * idx + 2];
+            nx.tmax = tmax[idx];
+        },
+        [&](uint64_t ray, const RayTrav &r) { occluded[ray] = r.best ? 1 : 0; });
     flush_counters<COUNT>(cnt, counters, CNT_ANY, nrays);
 }
 

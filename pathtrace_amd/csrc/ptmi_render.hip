@@ -262,96 +262,38 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
     if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)nq);
 }
 
-// extend for straight rays with one segment per call (max_steps == 1, no black hole), vote-scheduled like the batch
-// kernel extend_vote_kernel (ptmi_api.hip): persistent waves, one step type per iteration by vote, queue entries dealt
-// in chunks from one cursor, the next entry prefetched while the current ray is walked.  Same outputs as
-// render_extend_kernel: the hit into the path header, the advanced ray (tracer.go:226-228) back into the entry on a miss.
+// extend for straight rays with one segment per call (max_steps == 1, no black hole): persistent waves walking
+// vote-scheduled single steps (vote_walk, trav_device.hpp), queue entries dealt in chunks from one cursor.  Same outputs
+// as render_extend_kernel: the hit into the path header, the advanced ray (tracer.go:226-228) back into the entry on a miss.
+struct ExtendTag { uint32_t entry; float slot; };      // the slot word of the entry, kept as the bits it was read as
 template <int STACK>
 __global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Pool pl, RenderArgs ra, float4 *__restrict__ qray,
                                                                   uint32_t n, unsigned long long *cursor,
                                                                   unsigned long long *counters, int refill_min, int tri_bias,
                                                                   uint32_t chunk_rays) {
     __shared__ uint32_t smem[STACK * WAVE];
-    uint32_t *stack_base = smem + threadIdx.x;
-    const uint32_t lane = threadIdx.x;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float step = ra.p.step_size;
     TravCounters cnt;
-    RayTrav r;
-    r.cur = D_REF_DONE; r.exact = false; r.sp = 0; r.best = -1; r.best_t = 0.0f;
-    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
-    uint32_t my_entry = 0, next_entry = 0;
-    float my_slot = 0.f, next_slot = 0.f;      // the slot word of the entry, kept as the bits it was read as
-    float nox = 0.f, noy = 0.f, noz = 0.f, ndx = 0.f, ndy = 0.f, ndz = 0.f;
-    bool pending = false, have_next = false;
-    auto grab = [&]() -> unsigned long long {
-        unsigned long long v = 0;
-        if (lane == 0) v = atomicAdd(cursor, (unsigned long long)chunk_rays);
-        return v;
-    };
-    auto uniform = [&](unsigned long long v) -> uint64_t {
-        return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
-               (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
-    };
-    uint64_t chunk = uniform(grab()), chunk1 = uniform(grab());
-    unsigned long long inflight = grab();
-    uint32_t used = 0;
-    auto reserve = [&](uint32_t k) {
-        const uint64_t idx = k < chunk_rays ? chunk + k : chunk1 + (k - chunk_rays);
-        have_next = idx < n;
-        if (have_next) {
-            next_entry = (uint32_t)idx;
+    vote_walk<WAVE, false, false, ExtendTag>(
+        bvh, smem + threadIdx.x, n, cursor, refill_min, tri_bias, chunk_rays, cnt,
+        [&](uint64_t idx, NextRay &nx, ExtendTag &tag) {
             const float4 qa = qray[2 * (size_t)idx], qb = qray[2 * (size_t)idx + 1];
-            nox = qa.x; noy = qa.y; noz = qa.z; next_slot = qa.w; ndx = qb.x; ndy = qb.y; ndz = qb.z;
-        }
-    };
-    auto advance = [&](uint32_t taken) {
-        used += taken;
-        if (used >= chunk_rays) { used -= chunk_rays; chunk = chunk1; chunk1 = uniform(inflight); inflight = grab(); }
-    };
-    reserve(lane);
-    advance(WAVE);
-    for (;;) {
-        const bool at_inner = !(r.cur & D_REF_LEAF_BIT);
-        const bool at_tri = (r.cur & D_REF_LEAF_BIT) && r.cur != D_REF_DONE;
-        const bool idle = r.cur == D_REF_DONE;
-        const int nI = __popcll(__ballot(at_inner)), nT = __popcll(__ballot(at_tri));
-        const unsigned long long takers = __ballot(idle && have_next);
-        const int nR = __popcll(takers);
-        if (nI + nT == 0 || nR >= refill_min) {
-            if (idle && pending) {
-                uint32_t slot = f2u(my_slot);
-                if (slot >= pl.cap) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT); slot = 0; }
-                float *h1 = (float *)(pl.hdr + (size_t)slot * HQ + 1);                 // word 0 (tracker entry 0) is shade's
-                const bool hit = r.best >= 0;
-                h1[1] = i2f(hit ? HS_HIT : HS_MISS); h1[2] = i2f(r.best); h1[3] = hit ? r.best_t : 0.0f;
-                if (!hit) {                                                            // :226-228, as render_extend_kernel
-                    const V3 o = add(mk(r.ox, r.oy, r.oz), scale(mk(r.dx, r.dy, r.dz), step));
-                    qray[2 * (size_t)my_entry] = make_float4(o.x, o.y, o.z, my_slot);
-                    qray[2 * (size_t)my_entry + 1] = make_float4(r.dx, r.dy, r.dz, 0.0f);
-                }
-                pending = false;
+            tag.entry = (uint32_t)idx; tag.slot = qa.w;
+            nx.ox = qa.x; nx.oy = qa.y; nx.oz = qa.z; nx.dx = qb.x; nx.dy = qb.y; nx.dz = qb.z; nx.tmax = step;
+        },
+        [&](const ExtendTag &tag, const RayTrav &r) {
+            uint32_t slot = f2u(tag.slot);
+            if (slot >= pl.cap) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT); slot = 0; }
+            float *h1 = (float *)(pl.hdr + (size_t)slot * HQ + 1);                 // word 0 (tracker entry 0) is shade's
+            const bool hit = r.best >= 0;
+            h1[1] = i2f(hit ? HS_HIT : HS_MISS); h1[2] = i2f(r.best); h1[3] = hit ? r.best_t : 0.0f;
+            if (!hit) {                                                            // :226-228, as render_extend_kernel
+                const V3 o = add(mk(r.ox, r.oy, r.oz), scale(mk(r.dx, r.dy, r.dz), step));
+                qray[2 * (size_t)tag.entry] = make_float4(o.x, o.y, o.z, tag.slot);
+                qray[2 * (size_t)tag.entry + 1] = make_float4(r.dx, r.dy, r.dz, 0.0f);
             }
-            if (nR == 0) break;
-            if (idle && have_next) {
-                my_entry = next_entry; my_slot = next_slot; pending = true;
-                trav_init(r, bvh, nox, noy, noz, ndx, ndy, ndz, step);
-                reserve(used + (uint32_t)__popcll(takers & lt_mask));
-            }
-            advance((uint32_t)nR);
-            continue;
-        }
-        if (nI > 0 && (nT == 0 || nI + tri_bias >= nT)) {
-            if (__any(at_inner && r.exact)) {
-                if (at_inner) vote_inner_step<WAVE, false, true>(bvh, stack_base, r, cnt);
-            } else {
-                if (at_inner) vote_inner_step<WAVE, false, false>(bvh, stack_base, r, cnt);
-            }
-        } else {
-            if (at_tri) vote_tri_step<WAVE, false>(bvh, stack_base, r, cnt);
-        }
-    }
-    if (blockIdx.x == 0 && lane == 0 && n) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)n);
+        });
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)n);
 }
 
 // ------------------------------------------------------------------------------------------ connect
@@ -413,92 +355,33 @@ __global__ __launch_bounds__(WAVE) void render_connect_retry_kernel(DevBVH bvh, 
     else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
 }
 
-// connect, vote-scheduled (the scheduling of connect_vote_kernel, ptmi_api.hip): persistent waves, one step type per
-// iteration chosen by vote, shadow rays dealt in chunks from one cursor over the buckets laid end to end (a chunk is
-// nearly always of one kind), the next ray prefetched while the current one is walked.
+// connect: persistent waves walking vote-scheduled single steps (vote_walk, trav_device.hpp), shadow rays dealt in
+// chunks from one cursor over the buckets laid end to end (a chunk is nearly always of one kind).
 template <int STACK>
 __global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, Pool pl, ShadowCounts sn, unsigned long long *cursor,
                                                                    unsigned long long *counters, int refill_min, int tri_bias,
                                                                    uint32_t chunk_rays) {
     __shared__ uint32_t smem[STACK * WAVE];
-    uint32_t *stack_base = smem + threadIdx.x;
-    const uint32_t lane = threadIdx.x;
     uint64_t n = 0;
 #pragma unroll
     for (int k = 0; k < NSB; ++k) n += sn.n[k];
     const uint32_t ntargets = pl.cap * (uint32_t)pl.nframes * (uint32_t)pl.nshadow;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     TravCounters cnt;
-    RayTrav r;
-    r.cur = D_REF_DONE; r.exact = false; r.sp = 0; r.best = 0; r.best_t = 0.0f;
-    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
-    uint32_t my_target = 0, next_target = 0;
-    float nox = 0.f, noy = 0.f, noz = 0.f, ndx = 0.f, ndy = 0.f, ndz = 0.f, ntm = 0.f;
-    bool pending = false, have_next = false;
-    auto grab = [&]() -> unsigned long long {
-        unsigned long long v = 0;
-        if (lane == 0) v = atomicAdd(cursor, (unsigned long long)chunk_rays);
-        return v;
-    };
-    auto uniform = [&](unsigned long long v) -> uint64_t {
-        return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
-               (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
-    };
-    uint64_t chunk = uniform(grab()), chunk1 = uniform(grab());
-    unsigned long long inflight = grab();
-    uint32_t used = 0;
-    auto reserve = [&](uint32_t k) {
-        const uint64_t idx = k < chunk_rays ? chunk + k : chunk1 + (k - chunk_rays);
-        have_next = idx < n;
-        if (have_next) {
+    vote_walk<WAVE, true, false, uint32_t>(
+        bvh, smem + threadIdx.x, n, cursor, refill_min, tri_bias, chunk_rays, cnt,
+        [&](uint64_t idx, NextRay &nx, uint32_t &target) {
             uint32_t rem = (uint32_t)idx, b = 0;             // bucket b, entry rem
 #pragma unroll
             for (int q = 0; q < NSB - 1; ++q) if (b == (uint32_t)q && rem >= sn.n[q]) { rem -= sn.n[q]; b = q + 1; }
             const size_t e = (size_t)b * pl.cap + rem;
             const float4 a = pl.q_sray_a[e], bb = pl.q_sray_b[e];
-            nox = a.x; noy = a.y; noz = a.z; ntm = a.w; ndx = bb.x; ndy = bb.y; ndz = bb.z; next_target = f2u(bb.w);
-        }
-    };
-    auto advance = [&](uint32_t taken) {
-        used += taken;
-        if (used >= chunk_rays) { used -= chunk_rays; chunk = chunk1; chunk1 = uniform(inflight); inflight = grab(); }
-    };
-    reserve(lane);
-    advance(WAVE);
-    for (;;) {
-        const bool at_inner = !(r.cur & D_REF_LEAF_BIT);
-        const bool at_tri = (r.cur & D_REF_LEAF_BIT) && r.cur != D_REF_DONE;
-        const bool idle = r.cur == D_REF_DONE;
-        const int nI = __popcll(__ballot(at_inner)), nT = __popcll(__ballot(at_tri));
-        const unsigned long long takers = __ballot(idle && have_next);
-        const int nR = __popcll(takers);
-        if (nI + nT == 0 || nR >= refill_min) {
-            if (idle && pending) {
-                if (my_target < ntargets) ((uint32_t *)pl.sh)[(size_t)my_target * 4 + 3] = r.best ? 1u : 0u;
-                else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
-                pending = false;
-            }
-            if (nR == 0) break;
-            if (idle && have_next) {
-                my_target = next_target; pending = true;
-                trav_init(r, bvh, nox, noy, noz, ndx, ndy, ndz, ntm);
-                r.best = 0;
-                reserve(used + (uint32_t)__popcll(takers & lt_mask));
-            }
-            advance((uint32_t)nR);
-            continue;
-        }
-        if (nI > 0 && (nT == 0 || nI + tri_bias >= nT)) {
-            if (__any(at_inner && r.exact)) {
-                if (at_inner) vote_inner_step_any<WAVE, false, true>(bvh, stack_base, r, cnt);
-            } else {
-                if (at_inner) vote_inner_step_any<WAVE, false, false>(bvh, stack_base, r, cnt);
-            }
-        } else {
-            if (at_tri) vote_tri_step_any<WAVE, false>(bvh, stack_base, r, cnt);
-        }
-    }
-    if (blockIdx.x == 0 && lane == 0 && n) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
+            nx.ox = a.x; nx.oy = a.y; nx.oz = a.z; nx.tmax = a.w; nx.dx = bb.x; nx.dy = bb.y; nx.dz = bb.z; target = f2u(bb.w);
+        },
+        [&](uint32_t target, const RayTrav &r) {
+            if (target < ntargets) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = r.best ? 1u : 0u;
+            else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
+        });
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
 }
 
 // ------------------------------------------------------------------------------------------ shade

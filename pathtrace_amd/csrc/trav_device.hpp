@@ -435,6 +435,99 @@ __device__ __forceinline__ void vote_tri_step_any(const DevBVH &bvh, uint32_t *s
     else r.cur = r.cur + 1u;
 }
 
+// ---- the vote-scheduled walk of a persistent wave -------------------------------------------------------
+// Shared by the batch kernels (ptmi_api.hip) and the integrator's extend / connect (ptmi_render.hip); they differ only
+// in where a ray comes from (`fetch(idx, ray, tag)`) and where its answer goes (`store(tag, r)`).
+//
+// Every iteration the wave counts its lanes at an inner node (I), at a triangle record (T) and idle with a ray in
+// reserve (R), and runs ONE step type for the lanes in that state: refill when `refill_min` lanes are idle (or nothing
+// else is left), otherwise the majority of I / T (I wins when nI + tri_bias >= nT).  A waiting state's population only
+// grows until it is served, so no lane starves.
+//
+// Rays are dealt in chunks of `chunk_rays` from one global cursor, in batch order: at any moment the whole chip works
+// on neighbouring rays, which keeps the touched part of the tree in L2 (dealing chunks statically per wave was measured
+// 25 % slower for that reason).  The cursor is only touched once per chunk and two chunks ahead of use, and each lane
+// keeps its NEXT ray prefetched in registers, loaded while the current one is walked, so neither the atomic nor the
+// ray fetch is ever waited for.  The loop ends when the cursor has passed n and every lane has drained and stored its
+// result.  ANY selects QuickCheckIntersection's walk (r.best = 1 when occluded), otherwise CheckIntersection's.
+// Returns the number of rays this lane walked.  The workgroup is one wave.
+struct NextRay { float ox, oy, oz, dx, dy, dz, tmax; };
+
+template <int BLOCK, bool ANY, bool COUNT, typename Tag, typename Fetch, typename Store>
+__device__ __forceinline__ uint32_t vote_walk(const DevBVH &bvh, uint32_t *stack_base, uint64_t n, unsigned long long *cursor,
+                                              int refill_min, int tri_bias, uint32_t chunk_rays, TravCounters &cnt,
+                                              Fetch fetch, Store store) {
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    RayTrav r;
+    r.cur = D_REF_DONE; r.exact = false; r.sp = 0; r.best = ANY ? 0 : -1; r.best_t = 0.0f;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+    Tag my_tag{}, next_tag{};
+    NextRay nx = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool pending = false, have_next = false;
+    uint32_t nrays = 0;
+    // chunk pipeline (wave-uniform): `chunk` is being handed out, `chunk1` is ready, `inflight` (lane 0) is on its way
+    auto grab = [&]() -> unsigned long long {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(cursor, (unsigned long long)chunk_rays);
+        return v;
+    };
+    auto uniform = [&](unsigned long long v) -> uint64_t {
+        return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+               (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    };
+    uint64_t chunk = uniform(grab()), chunk1 = uniform(grab());
+    unsigned long long inflight = grab();
+    uint32_t used = 0;                      // rays of `chunk` already reserved
+    auto reserve = [&](uint32_t k) {        // k-th ray counted from the start of `chunk` -> prefetch registers
+        const uint64_t idx = k < chunk_rays ? chunk + k : chunk1 + (k - chunk_rays);
+        have_next = idx < n;
+        if (have_next) fetch(idx, nx, next_tag);
+    };
+    auto advance = [&](uint32_t taken) {
+        used += taken;
+        if (used >= chunk_rays) {
+            used -= chunk_rays;
+            chunk = chunk1;
+            chunk1 = uniform(inflight);
+            inflight = grab();
+        }
+    };
+    reserve(lane);
+    advance(64);
+    for (;;) {
+        const bool at_inner = !(r.cur & D_REF_LEAF_BIT);
+        const bool at_tri = (r.cur & D_REF_LEAF_BIT) && r.cur != D_REF_DONE;
+        const bool idle = r.cur == D_REF_DONE;
+        const int nI = __popcll(__ballot(at_inner)), nT = __popcll(__ballot(at_tri));
+        const unsigned long long takers = __ballot(idle && have_next);
+        const int nR = __popcll(takers);
+        if (nI + nT == 0 || nR >= refill_min) {
+            // ---- R step: store finished results, start the prefetched rays, reserve the next ones ----
+            if (idle && pending) { store(my_tag, r); pending = false; }
+            if (nR == 0) break;             // nothing left to start, nothing in flight: the wave is done
+            if (idle && have_next) {
+                my_tag = next_tag; pending = true; ++nrays;
+                trav_init(r, bvh, nx.ox, nx.oy, nx.oz, nx.dx, nx.dy, nx.dz, nx.tmax);
+                if (ANY) r.best = 0;
+                reserve(used + (uint32_t)__popcll(takers & lt_mask));
+            }
+            advance((uint32_t)nR);
+            continue;
+        }
+        if (nI > 0 && (nT == 0 || nI + tri_bias >= nT)) {
+            if (__any(at_inner && r.exact)) {
+                if (at_inner) { if (ANY) vote_inner_step_any<BLOCK, COUNT, true>(bvh, stack_base, r, cnt); else vote_inner_step<BLOCK, COUNT, true>(bvh, stack_base, r, cnt); }
+            } else {
+                if (at_inner) { if (ANY) vote_inner_step_any<BLOCK, COUNT, false>(bvh, stack_base, r, cnt); else vote_inner_step<BLOCK, COUNT, false>(bvh, stack_base, r, cnt); }
+            }
+        } else {
+            if (at_tri) { if (ANY) vote_tri_step_any<BLOCK, COUNT>(bvh, stack_base, r, cnt); else vote_tri_step<BLOCK, COUNT>(bvh, stack_base, r, cnt); }
+        }
+    }
+    return nrays;
+}
+
 // QuickCheckIntersection (linear_bvh.go:202-250)
 template <int BLOCK, bool COUNT, bool EXACT>
 __device__ __forceinline__ bool any_hit_impl(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
