@@ -174,7 +174,7 @@ __device__ __forceinline__ void closest_hit_impl(const DevBVH &bvh, uint32_t *st
         while (!(cur & D_REF_LEAF_BIT)) {           // descend until every lane of the wave is at a leaf (or done)
             if (COUNT) cnt.inner++;
             const float4 *p = bvh.nodes + (size_t)cur * 4;
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2]; const float2 q3 = *(const float2 *)(p + 3);   // the refs: 8 of the quarter's 16 bytes
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
             float d1 = slab_sel<EXACT>(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, best_t);
             float d2 = slab_sel<EXACT>(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, best_t);
             uint32_t i = __float_as_uint(q3.x), j = __float_as_uint(q3.y);
@@ -205,7 +205,7 @@ __device__ __forceinline__ void closest_hit_impl(const DevBVH &bvh, uint32_t *st
         if (!(cur & D_REF_LEAF_BIT)) {
             if (COUNT) cnt.inner++;
             const float4 *p = bvh.nodes + (size_t)cur * 4;
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2]; const float2 q3 = *(const float2 *)(p + 3);   // the refs: 8 of the quarter's 16 bytes
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
             float d1 = slab_sel<EXACT>(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, best_t);
             float d2 = slab_sel<EXACT>(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, best_t);
             uint32_t i = __float_as_uint(q3.x), j = __float_as_uint(q3.y);
@@ -319,7 +319,7 @@ template <int BLOCK, bool COUNT, bool EXACT>
 __device__ __forceinline__ void vote_inner_step(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
     if (COUNT) cnt.inner++;
     const float4 *p = bvh.nodes + (size_t)r.cur * 4;
-    const float4 q0 = p[0], q1 = p[1], q2 = p[2]; const float2 q3 = *(const float2 *)(p + 3);   // the refs: 8 of the quarter's 16 bytes
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
     float d1, d2;
     if (EXACT) {
         d1 = slab(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.best_t);
@@ -383,7 +383,7 @@ template <int BLOCK, bool COUNT, bool EXACT>
 __device__ __forceinline__ void vote_inner_step_any(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
     if (COUNT) cnt.inner++;
     const float4 *p = bvh.nodes + (size_t)r.cur * 4;
-    const float4 q0 = p[0], q1 = p[1], q2 = p[2]; const float2 q3 = *(const float2 *)(p + 3);   // the refs: 8 of the quarter's 16 bytes
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
     const float step = r.best_t;
     float d1, d2;
     if (EXACT) {
@@ -540,7 +540,7 @@ __device__ __forceinline__ bool any_hit_impl(const DevBVH &bvh, uint32_t *stack_
         while (!(cur & D_REF_LEAF_BIT)) {
             if (COUNT) cnt.inner++;
             const float4 *p = bvh.nodes + (size_t)cur * 4;
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2]; const float2 q3 = *(const float2 *)(p + 3);   // the refs: 8 of the quarter's 16 bytes
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
             float d1 = slab_sel<EXACT>(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, step);
             float d2 = slab_sel<EXACT>(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, step);
             uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
@@ -573,7 +573,7 @@ __device__ __forceinline__ bool any_hit_impl(const DevBVH &bvh, uint32_t *stack_
         if (!(cur & D_REF_LEAF_BIT)) {
             if (COUNT) cnt.inner++;
             const float4 *p = bvh.nodes + (size_t)cur * 4;
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2]; const float2 q3 = *(const float2 *)(p + 3);   // the refs: 8 of the quarter's 16 bytes
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
             float d1 = slab_sel<EXACT>(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, step);
             float d2 = slab_sel<EXACT>(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, step);
             uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
@@ -619,7 +619,7 @@ __device__ __forceinline__ int any_hit_or_bail_impl(const DevBVH &bvh, uint32_t 
         if (__popcll(__ballot(1)) <= bail_lanes) return 2;
         while (!(cur & D_REF_LEAF_BIT)) {
             const float4 *p = bvh.nodes + (size_t)cur * 4;
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2]; const float2 q3 = *(const float2 *)(p + 3);
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
             float d1 = slab_sel<EXACT>(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, step);
             float d2 = slab_sel<EXACT>(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, step);
             uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
