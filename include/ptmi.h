@@ -18,6 +18,11 @@
  *     context's device itself (hipSetDevice), so Go's goroutine->thread migration is harmless.
  *   - entry points ending in _dev take DEVICE pointers on the context's GPU and enqueue on
  *     `stream` (a hipStream_t passed as void*, NULL = default stream) without synchronising.
+ *     The batch queries (ptmi_closest_hit_dev, ptmi_any_hit_dev) may be issued on different
+ *     streams of one context and overlap on the device: every launch has its own ray cursor
+ *     (a ring of 64, so at most 64 such launches of one context may be in flight at once).
+ *   - a new tree (ptmi_build_bvh, ptmi_upload_bvh, ptmi_upload_host_bvh) waits for the device
+ *     and invalidates the uploaded scene: call ptmi_upload_scene again before rendering.
  *   - vectors are packed xyz float32 triples (the reference's Vec3, vec3.go:9-11).
  */
 #ifndef PTMI_H

@@ -37,6 +37,7 @@ int ensure_stage(ptmi_ctx *ctx, size_t bytes) {
 // ------------------------------------------------------------------------------------ kernels
 
 constexpr int WAVE = 64;
+constexpr uint64_t PTMI_MAX_RAYS_PER_CALL = 0x3FFFFFFFull * WAVE;   // the one-shot kernels' grid is n / 64 workgroups
 
 template <bool COUNT>
 __device__ __forceinline__ void flush_counters(const TravCounters &c, unsigned long long *counters, int which_query,
@@ -137,60 +138,56 @@ __global__ __launch_bounds__(WAVE) void connect_vote_kernel(DevBVH bvh, const fl
     flush_counters<COUNT>(cnt, counters, CNT_ANY, nrays);
 }
 
+// Where a launch keeps its device-side scratch: the work counters (CNT_SHARDS lines) and this launch's ray cursor.
+struct LaunchScratch { unsigned long long *counters, *cursor; };
+static LaunchScratch ctx_scratch(ptmi_ctx *ctx) { return LaunchScratch{ctx->d_counters, ctx->next_cursor()}; }
+
 template <int STACK>
-static void launch_extend(ptmi_ctx *ctx, const float *o, const float *d, const float *tmax, uint64_t n, int32_t *prim,
-                          float *t, hipStream_t s) {
+static int launch_extend(ptmi_ctx *ctx, const LaunchScratch &sc, const float *o, const float *d, const float *tmax, uint64_t n,
+                         int32_t *prim, float *t, hipStream_t s) {
     dim3 grid((unsigned)((n + WAVE - 1) / WAVE)), block(WAVE);
     if (ctx->extend_variant == 0) {      // one-shot kernel (A/B reference, PTMI_EXTEND_VARIANT=0)
         if (ctx->counting)
-            hipLaunchKernelGGL((extend_kernel<STACK, true>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t,
-                               ctx->d_counters);
+            hipLaunchKernelGGL((extend_kernel<STACK, true>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t, sc.counters);
         else
-            hipLaunchKernelGGL((extend_kernel<STACK, false>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t,
-                               ctx->d_counters);
-        return;
+            hipLaunchKernelGGL((extend_kernel<STACK, false>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t, sc.counters);
+        return PTMI_OK;
     }
     // persistent vote-scheduled kernel: one resident round of waves (the LDS stack bounds how many fit)
-    int per_cu = 0;
     const void *fn = ctx->counting ? (const void *)extend_vote_kernel<STACK, true> : (const void *)extend_vote_kernel<STACK, false>;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WAVE, 0) != hipSuccess || per_cu < 1) per_cu = 8;
-    per_cu = std::min(per_cu, ctx->persist_waves_per_cu);
-    unsigned long long *cursor = ctx->d_counters + CNT_CURSOR;
-    (void)hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s);
+    const int per_cu = std::min(ctx->waves_per_cu(fn, WAVE), ctx->persist_waves_per_cu);
+    PTMI_HIP(ctx, hipMemsetAsync(sc.cursor, 0, sizeof(unsigned long long), s));
     dim3 pgrid((unsigned)std::min<uint64_t>(grid.x, (uint64_t)ctx->num_cus * per_cu));
     if (ctx->counting)
         hipLaunchKernelGGL((extend_vote_kernel<STACK, true>), pgrid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t,
-                           ctx->d_counters, cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
+                           sc.counters, sc.cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
     else
         hipLaunchKernelGGL((extend_vote_kernel<STACK, false>), pgrid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, prim, t,
-                           ctx->d_counters, cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
+                           sc.counters, sc.cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
+    return PTMI_OK;
 }
 template <int STACK>
-static void launch_connect(ptmi_ctx *ctx, const float *o, const float *d, const float *tmax, uint64_t n, uint8_t *occ,
-                           hipStream_t s) {
+static int launch_connect(ptmi_ctx *ctx, const LaunchScratch &sc, const float *o, const float *d, const float *tmax, uint64_t n,
+                          uint8_t *occ, hipStream_t s) {
     dim3 grid((unsigned)((n + WAVE - 1) / WAVE)), block(WAVE);
     if (ctx->extend_variant == 0) {      // one-shot kernel (A/B reference, PTMI_EXTEND_VARIANT=0)
         if (ctx->counting)
-            hipLaunchKernelGGL((connect_kernel<STACK, true>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
-                               ctx->d_counters);
+            hipLaunchKernelGGL((connect_kernel<STACK, true>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ, sc.counters);
         else
-            hipLaunchKernelGGL((connect_kernel<STACK, false>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
-                               ctx->d_counters);
-        return;
+            hipLaunchKernelGGL((connect_kernel<STACK, false>), grid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ, sc.counters);
+        return PTMI_OK;
     }
-    int per_cu = 0;
     const void *fn = ctx->counting ? (const void *)connect_vote_kernel<STACK, true> : (const void *)connect_vote_kernel<STACK, false>;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WAVE, 0) != hipSuccess || per_cu < 1) per_cu = 8;
-    per_cu = std::min(per_cu, ctx->persist_waves_per_cu);
-    unsigned long long *cursor = ctx->d_counters + CNT_CURSOR;
-    (void)hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s);
+    const int per_cu = std::min(ctx->waves_per_cu(fn, WAVE), ctx->persist_waves_per_cu);
+    PTMI_HIP(ctx, hipMemsetAsync(sc.cursor, 0, sizeof(unsigned long long), s));
     dim3 pgrid((unsigned)std::min<uint64_t>(grid.x, (uint64_t)ctx->num_cus * per_cu));
     if (ctx->counting)
         hipLaunchKernelGGL((connect_vote_kernel<STACK, true>), pgrid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
-                           ctx->d_counters, cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
+                           sc.counters, sc.cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
     else
         hipLaunchKernelGGL((connect_vote_kernel<STACK, false>), pgrid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
-                           ctx->d_counters, cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
+                           sc.counters, sc.cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
+    return PTMI_OK;
 }
 
 // ------------------------------------------------------------------------------------ context
@@ -250,7 +247,7 @@ static void free_bvh_device(ptmi_ctx *ctx) {
     ctx->have_bvh = false;
 }
 
-namespace ptmi { void free_scene(ptmi_ctx *ctx); }
+namespace ptmi { void free_scene(ptmi_ctx *ctx); void invalidate_scene(ptmi_ctx *ctx); }
 
 extern "C" void ptmi_destroy(ptmi_ctx *ctx) {
     if (!ctx) return;
@@ -266,13 +263,20 @@ extern "C" void ptmi_destroy(ptmi_ctx *ctx) {
 
 // ------------------------------------------------------------------------------------ BVH
 
-static int upload_packed(ptmi_ctx *ctx, const float *verts, uint64_t nverts, const uint32_t *tri_idx, uint64_t ntris) {
+// Packs `lin` and replaces the context's tree with it.  The context only changes once packing has succeeded; from
+// then on the old tree is gone, and so is the scene that was uploaded for the old mesh (its per-triangle records are
+// sized for that mesh): render calls return PTMI_ERR_NO_SCENE until ptmi_upload_scene is called again.
+static int upload_packed(ptmi_ctx *ctx, LinearBVH &lin, const float *verts, uint64_t nverts, const uint32_t *tri_idx, uint64_t ntris) {
     const char *msg = "";
     PackedBVH packed;
-    int rc = pack_bvh(ctx->lin, verts, tri_idx, packed, &msg);
+    int rc = pack_bvh(lin, verts, tri_idx, packed, &msg);
     if (rc) return set_err(ctx, rc, std::string("pack_bvh: ") + msg);
     PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    PTMI_HIP(ctx, hipDeviceSynchronize());          // no kernel of this context may still be walking the old tree
     free_bvh_device(ctx);
+    ptmi::invalidate_scene(ctx);
+    ctx->lin.nodes.swap(lin.nodes);
+    ctx->lin.tri_ids.swap(lin.tri_ids);
     size_t nb = packed.nodes.size() * sizeof(PackedNode), tb = packed.tris.size() * sizeof(PackedTri);
     PTMI_HIP(ctx, hipMalloc((void **)&ctx->d_nodes, nb ? nb : 64));
     PTMI_HIP(ctx, hipMalloc((void **)&ctx->d_tris, tb ? tb : 48));
@@ -381,9 +385,10 @@ extern "C" int ptmi_host_bvh_stats(const ptmi_host_bvh *bvh, PtBvhStats *out) {
 
 extern "C" int ptmi_upload_host_bvh(ptmi_ctx *ctx, const ptmi_host_bvh *bvh) {
     if (!ctx || !bvh) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_host_bvh: null argument");
-    ctx->lin = bvh->lin;
-    ctx->build_ms = bvh->build_ms;
-    return upload_packed(ctx, bvh->verts.data(), bvh->verts.size() / 3, bvh->tri_idx.data(), bvh->tri_idx.size() / 3);
+    LinearBVH lin = bvh->lin;
+    int rc = upload_packed(ctx, lin, bvh->verts.data(), bvh->verts.size() / 3, bvh->tri_idx.data(), bvh->tri_idx.size() / 3);
+    if (rc == PTMI_OK) ctx->build_ms = bvh->build_ms;
+    return rc;
 }
 
 extern "C" int ptmi_build_bvh(ptmi_ctx *ctx, const float *verts_xyz, uint64_t nverts, const uint32_t *tri_idx,
@@ -394,10 +399,10 @@ extern "C" int ptmi_build_bvh(ptmi_ctx *ctx, const float *verts_xyz, uint64_t nv
     LinearBVH lin;
     int rc = build_linear_bvh(verts_xyz, nverts, tri_idx, ntris, bounds, threshold, depth, lin, &msg);
     if (rc) return set_err(ctx, rc == -5 ? PTMI_ERR_DEPTH : PTMI_ERR_INVALID, std::string("ptmi_build_bvh: ") + msg);
-    ctx->lin.nodes.swap(lin.nodes);
-    ctx->lin.tri_ids.swap(lin.tri_ids);
-    ctx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return upload_packed(ctx, verts_xyz, nverts, tri_idx, ntris);
+    const double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    rc = upload_packed(ctx, lin, verts_xyz, nverts, tri_idx, ntris);
+    if (rc == PTMI_OK) ctx->build_ms = build_ms;
+    return rc;
 }
 
 extern "C" int ptmi_upload_bvh(ptmi_ctx *ctx, const float *verts_xyz, uint64_t nverts, const uint32_t *tri_idx,
@@ -422,10 +427,9 @@ extern "C" int ptmi_upload_bvh(ptmi_ctx *ctx, const float *verts_xyz, uint64_t n
     const char *msg = "";
     int rc = validate_linear_bvh(lin, ntris, &msg);
     if (rc) return set_err(ctx, rc == -5 ? PTMI_ERR_DEPTH : PTMI_ERR_INVALID, std::string("ptmi_upload_bvh: ") + msg);
-    ctx->lin.nodes.swap(lin.nodes);
-    ctx->lin.tri_ids.swap(lin.tri_ids);
-    ctx->build_ms = 0.0;
-    return upload_packed(ctx, verts_xyz, nverts, tri_idx, ntris);
+    rc = upload_packed(ctx, lin, verts_xyz, nverts, tri_idx, ntris);
+    if (rc == PTMI_OK) ctx->build_ms = 0.0;
+    return rc;
 }
 
 extern "C" int ptmi_bvh_sizes(ptmi_ctx *ctx, uint64_t *n_nodes, uint64_t *n_tri_ids) {
@@ -454,27 +458,31 @@ extern "C" int ptmi_bvh_stats(ptmi_ctx *ctx, PtBvhStats *out) {
 
 // ------------------------------------------------------------------------------------ queries
 
-static int dispatch_extend(ptmi_ctx *ctx, const float *o, const float *d, const float *tmax, uint64_t n, int32_t *prim,
-                           float *t, hipStream_t s) {
-    if (n > 0x3FFFFFFFull * WAVE) return set_err(ctx, PTMI_ERR_INVALID, "too many rays in one call");
+static int dispatch_extend(ptmi_ctx *ctx, const LaunchScratch &sc, const float *o, const float *d, const float *tmax, uint64_t n,
+                           int32_t *prim, float *t, hipStream_t s) {
+    if (n > PTMI_MAX_RAYS_PER_CALL) return set_err(ctx, PTMI_ERR_INVALID, "too many rays in one call");
     const int dep = ctx->max_depth;
-    if (dep <= 16) launch_extend<16>(ctx, o, d, tmax, n, prim, t, s);
-    else if (dep <= 24) launch_extend<24>(ctx, o, d, tmax, n, prim, t, s);
-    else if (dep <= 32) launch_extend<32>(ctx, o, d, tmax, n, prim, t, s);
-    else if (dep <= 48) launch_extend<48>(ctx, o, d, tmax, n, prim, t, s);
-    else launch_extend<64>(ctx, o, d, tmax, n, prim, t, s);
+    int rc;
+    if (dep <= 16) rc = launch_extend<16>(ctx, sc, o, d, tmax, n, prim, t, s);
+    else if (dep <= 24) rc = launch_extend<24>(ctx, sc, o, d, tmax, n, prim, t, s);
+    else if (dep <= 32) rc = launch_extend<32>(ctx, sc, o, d, tmax, n, prim, t, s);
+    else if (dep <= 48) rc = launch_extend<48>(ctx, sc, o, d, tmax, n, prim, t, s);
+    else rc = launch_extend<64>(ctx, sc, o, d, tmax, n, prim, t, s);
+    if (rc) return rc;
     PTMI_HIP(ctx, hipGetLastError());
     return PTMI_OK;
 }
-static int dispatch_connect(ptmi_ctx *ctx, const float *o, const float *d, const float *tmax, uint64_t n, uint8_t *occ,
-                            hipStream_t s) {
-    if (n > 0x3FFFFFFFull * WAVE) return set_err(ctx, PTMI_ERR_INVALID, "too many rays in one call");
+static int dispatch_connect(ptmi_ctx *ctx, const LaunchScratch &sc, const float *o, const float *d, const float *tmax, uint64_t n,
+                            uint8_t *occ, hipStream_t s) {
+    if (n > PTMI_MAX_RAYS_PER_CALL) return set_err(ctx, PTMI_ERR_INVALID, "too many rays in one call");
     const int dep = ctx->max_depth;
-    if (dep <= 16) launch_connect<16>(ctx, o, d, tmax, n, occ, s);
-    else if (dep <= 24) launch_connect<24>(ctx, o, d, tmax, n, occ, s);
-    else if (dep <= 32) launch_connect<32>(ctx, o, d, tmax, n, occ, s);
-    else if (dep <= 48) launch_connect<48>(ctx, o, d, tmax, n, occ, s);
-    else launch_connect<64>(ctx, o, d, tmax, n, occ, s);
+    int rc;
+    if (dep <= 16) rc = launch_connect<16>(ctx, sc, o, d, tmax, n, occ, s);
+    else if (dep <= 24) rc = launch_connect<24>(ctx, sc, o, d, tmax, n, occ, s);
+    else if (dep <= 32) rc = launch_connect<32>(ctx, sc, o, d, tmax, n, occ, s);
+    else if (dep <= 48) rc = launch_connect<48>(ctx, sc, o, d, tmax, n, occ, s);
+    else rc = launch_connect<64>(ctx, sc, o, d, tmax, n, occ, s);
+    if (rc) return rc;
     PTMI_HIP(ctx, hipGetLastError());
     return PTMI_OK;
 }
@@ -486,7 +494,7 @@ extern "C" int ptmi_closest_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const flo
     if (n == 0) return PTMI_OK;
     if (!o_xyz || !d_xyz || !tmax || !prim_id || !t) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_closest_hit_dev: null buffer");
     PTMI_HIP(ctx, hipSetDevice(ctx->device));
-    return dispatch_extend(ctx, o_xyz, d_xyz, tmax, n, prim_id, t, (hipStream_t)stream);
+    return dispatch_extend(ctx, ctx_scratch(ctx), o_xyz, d_xyz, tmax, n, prim_id, t, (hipStream_t)stream);
 }
 
 extern "C" int ptmi_any_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n,
@@ -496,7 +504,7 @@ extern "C" int ptmi_any_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const float *
     if (n == 0) return PTMI_OK;
     if (!o_xyz || !d_xyz || !tmax || !occluded) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_any_hit_dev: null buffer");
     PTMI_HIP(ctx, hipSetDevice(ctx->device));
-    return dispatch_connect(ctx, o_xyz, d_xyz, tmax, n, occluded, (hipStream_t)stream);
+    return dispatch_connect(ctx, ctx_scratch(ctx), o_xyz, d_xyz, tmax, n, occluded, (hipStream_t)stream);
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -519,7 +527,7 @@ extern "C" int ptmi_closest_hit(ptmi_ctx *ctx, const float *o_xyz, const float *
     PTMI_HIP(ctx, hipMemcpyAsync(dO, o_xyz, n * 12, hipMemcpyHostToDevice, s));
     PTMI_HIP(ctx, hipMemcpyAsync(dD, d_xyz, n * 12, hipMemcpyHostToDevice, s));
     PTMI_HIP(ctx, hipMemcpyAsync(dT, tmax, n * 4, hipMemcpyHostToDevice, s));
-    rc = dispatch_extend(ctx, dO, dD, dT, n, dP, dt, s);
+    rc = dispatch_extend(ctx, ctx_scratch(ctx), dO, dD, dT, n, dP, dt, s);
     if (rc) return rc;
     PTMI_HIP(ctx, hipMemcpyAsync(prim_id, dP, n * 4, hipMemcpyDeviceToHost, s));
     PTMI_HIP(ctx, hipMemcpyAsync(t, dt, n * 4, hipMemcpyDeviceToHost, s));
@@ -544,7 +552,7 @@ extern "C" int ptmi_any_hit(ptmi_ctx *ctx, const float *o_xyz, const float *d_xy
     PTMI_HIP(ctx, hipMemcpyAsync(dO, o_xyz, n * 12, hipMemcpyHostToDevice, s));
     PTMI_HIP(ctx, hipMemcpyAsync(dD, d_xyz, n * 12, hipMemcpyHostToDevice, s));
     PTMI_HIP(ctx, hipMemcpyAsync(dT, tmax, n * 4, hipMemcpyHostToDevice, s));
-    rc = dispatch_connect(ctx, dO, dD, dT, n, dOcc, s);
+    rc = dispatch_connect(ctx, ctx_scratch(ctx), dO, dD, dT, n, dOcc, s);
     if (rc) return rc;
     PTMI_HIP(ctx, hipMemcpyAsync(occluded, dOcc, n, hipMemcpyDeviceToHost, s));
     PTMI_HIP(ctx, hipStreamSynchronize(s));

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ptmi.h"
@@ -18,8 +19,13 @@ enum {
     // tools/ubench_atomic.hip): 20 000 waves adding to one counter block take 0.25 ms for that alone.  The block is
     // therefore replicated CNT_SHARDS times, a workgroup adds to shard blockIdx % CNT_SHARDS and the host sums.
     CNT_SHARDS = 64,
-    CNT_CURSOR = CNT_SHARDS * CNT_WORDS,   // ray cursor of the persistent extend kernel: a line of its own
-    CNT_TOTAL_WORDS = (CNT_SHARDS + 1) * CNT_WORDS
+    // Ray cursors of the persistent batch kernels: a ring of lines, one line per launch.  _dev calls are asynchronous
+    // on caller-chosen streams, so two launches of one context can overlap on the device; each takes the next line
+    // of the ring (cleared on its own stream just before the launch), so up to CNT_CURSOR_LINES launches of a context
+    // may be in flight at once without sharing a cursor.
+    CNT_CURSOR_LINES = 64,
+    CNT_CURSOR = CNT_SHARDS * CNT_WORDS,
+    CNT_TOTAL_WORDS = (CNT_SHARDS + CNT_CURSOR_LINES) * CNT_WORDS
 };
 
 __device__ __forceinline__ unsigned long long *counter_shard(unsigned long long *counters) {
@@ -74,6 +80,19 @@ struct ptmi_ctx {
     // work counters
     bool counting = false;
     unsigned long long *d_counters = nullptr;
+    uint32_t cursor_seq = 0;            // next line of the cursor ring (calls on one ctx are serialised by the caller)
+    unsigned long long *next_cursor() { return d_counters + CNT_CURSOR + (size_t)(cursor_seq++ % CNT_CURSOR_LINES) * CNT_WORDS; }
+    // resident workgroups per CU of the persistent kernels, per kernel function (per context: contexts may be driven
+    // from different OS threads, and different devices may answer differently)
+    std::unordered_map<const void *, int> occupancy;
+    int waves_per_cu(const void *fn, int block_threads) {
+        auto it = occupancy.find(fn);
+        if (it != occupancy.end()) return it->second;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block_threads, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 8; }
+        occupancy.emplace(fn, per_cu);
+        return per_cu;
+    }
 
     float tight_min[3] = {0, 0, 0}, tight_max[3] = {0, 0, 0}, tight_margin = 0.0f;   // see DevBVH
     uint32_t tight_valid = 0;

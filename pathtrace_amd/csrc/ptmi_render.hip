@@ -11,9 +11,10 @@
 //              until the path needs another extend, a batch of shadow rays, or is finished
 //   connect  : any-hit for the shadow-ray queue (QuickCheckIntersection, linear_bvh.go:202)
 //   accumulate : per-pixel sums in sample order (Pixel.AddSample, renderer.go:59-61)
-// Queues are compacted with one atomic per wave (ballot + popcount); finished paths are re-filled
-// with fresh samples so the pool stays full.  All path state is SoA ([field][slot]) so that a wave's
-// accesses coalesce.
+// Queues are compacted with one atomic per workgroup (ballot + popcount per wave, summed in LDS); finished paths
+// are re-filled with fresh samples so the pool stays full.  Path state is an array of structures: a 128-byte header
+// line and 128-byte frame lines per path (queue order is arbitrary, so per-path records move whole lines where a
+// [field][slot] layout cost one sector per word).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -935,6 +936,15 @@ struct RenderState {
 };
 
 namespace ptmi {
+// the mesh under the scene changed (a new BVH was uploaded): the per-triangle records, UVs and emissive list belong
+// to the old mesh, so the scene has to be uploaded again before the next render call
+void invalidate_scene(ptmi_ctx *ctx) {
+    RenderState *rs = ctx->render;
+    if (!rs) return;
+    rs->have_scene = false;
+    for (void *p : {(void *)rs->d_uvs, (void *)rs->d_tex, (void *)rs->d_tex_pixels}) if (p) (void)hipFree(p);
+    rs->d_uvs = nullptr; rs->d_tex = nullptr; rs->d_tex_pixels = nullptr; rs->ntex = 0;
+}
 void free_scene(ptmi_ctx *ctx) {
     RenderState *rs = ctx->render;
     if (!rs) return;
@@ -1132,13 +1142,7 @@ template <int STACK>
 static void launch_render_extend_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, float4 *qray,
                                    uint32_t n, hipStream_t s) {
     if (!sc.has_bh && ra.p.max_steps == 1 && ctx->extend_vote) {
-        static int per_cu_cached = 0;
-        if (per_cu_cached == 0) {
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_extend_vote_kernel<STACK>, WAVE, 0) != hipSuccess || per_cu < 1) per_cu = 8;
-            per_cu_cached = per_cu;
-        }
-        const int per_cu = std::min(per_cu_cached, ctx->persist_waves_per_cu);
+        const int per_cu = std::min(ctx->waves_per_cu((const void *)render_extend_vote_kernel<STACK>, WAVE), ctx->persist_waves_per_cu);
         const uint32_t chunk = vote_chunk_for(ctx, n, per_cu);
         if (chunk) {
             const unsigned pgrid = (unsigned)std::min<uint64_t>((n + WAVE - 1) / WAVE, (uint64_t)ctx->num_cus * per_cu);
@@ -1169,13 +1173,7 @@ static void launch_render_connect_t(ptmi_ctx *ctx, const Pool &pl, const ShadowC
     unsigned blocks = 0;
     for (int b = 0; b < NSB; ++b) blocks += (n.n[b] + WAVE - 1) / WAVE;
     if (ctx->connect_vote) {
-        static int per_cu_cached = 0;
-        if (per_cu_cached == 0) {
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_connect_vote_kernel<STACK>, WAVE, 0) != hipSuccess || per_cu < 1) per_cu = 8;
-            per_cu_cached = per_cu;
-        }
-        const int per_cu = std::min(per_cu_cached, ctx->persist_waves_per_cu);
+        const int per_cu = std::min(ctx->waves_per_cu((const void *)render_connect_vote_kernel<STACK>, WAVE), ctx->persist_waves_per_cu);
         uint64_t nrays = 0;
         for (int b = 0; b < NSB; ++b) nrays += n.n[b];
         const uint32_t chunk = vote_chunk_for(ctx, nrays, per_cu);
@@ -1306,6 +1304,9 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
 
     // samples per pixel per batch: bound the per-sample output buffer (<= ~3 GiB, < 2^32/3 samples)
     uint32_t spp_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp_count, ((uint64_t)ctx->chunk_msamples << 20) / npix));
+    // the per-sample output is laid out [pixel][sample] over the WHOLE sample range, which only one pass produces
+    // (ptmi_render_samples caps a call at 2^28 samples, so the buffer stays bounded)
+    if (out_samples_host) spp_chunk = spp_count;
     const uint64_t max_total = npix * spp_chunk;
     // two lanes of 2^20 paths when there is enough work to keep both busy, else one
     const int lanes = (ctx->render_lanes >= 2 && max_total >= (1ull << 18)) ? 2 : 1;
@@ -1471,6 +1472,27 @@ extern "C" int ptmi_render_tiles_dev(ptmi_ctx *ctx, const PtCamera *camera, cons
             return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_tiles_dev: the tiles cover more pixels than the image has (overlap)");
     }
     first[ntiles] = (uint32_t)total;
+    {   // disjointness: sweep over the tiles sorted by x0; two tiles overlap iff their x- and y-ranges both do
+        // (accumulate_kernel's read-modify-write of a pixel is only race-free when one thread owns it)
+        std::vector<uint32_t> order(ntiles);
+        for (uint32_t k = 0; k < ntiles; ++k) order[k] = k;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return tiles_xywh[4 * (size_t)a] < tiles_xywh[4 * (size_t)b]; });
+        std::vector<uint32_t> active;           // tiles whose x-range reaches the current x0
+        for (uint32_t oi = 0; oi < ntiles; ++oi) {
+            const int32_t *t = tiles_xywh + 4 * (size_t)order[oi];
+            size_t keep = 0;
+            for (size_t j = 0; j < active.size(); ++j) {
+                const int32_t *u = tiles_xywh + 4 * (size_t)active[j];
+                if (u[0] + u[2] <= t[0]) continue;                      // ended before this tile starts
+                if (t[1] < u[1] + u[3] && u[1] < t[1] + t[3])
+                    return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_tiles_dev: tiles " + std::to_string(active[j]) + " and " +
+                                                          std::to_string(order[oi]) + " overlap");
+                active[keep++] = active[j];
+            }
+            active.resize(keep);
+            active.push_back(order[oi]);
+        }
+    }
     PTMI_HIP(ctx, hipSetDevice(ctx->device));
     const size_t b_first = ((size_t)(ntiles + 1) * 4 + 15) / 16 * 16, b_rect = (size_t)ntiles * 16;
     if (rs->tiles_bytes < b_first + b_rect) {

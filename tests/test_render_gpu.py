@@ -197,7 +197,9 @@ def test_tiles_in_one_call(gpu_ctx):
     for (x0, y0, w, h) in mine:
         mask[y0:y0 + h, x0:x0 + w] = True
     assert torch.equal(a[mask], ref[mask]) and bool((c[mask] == spp).all()) and bool((c[~mask] == 0).all())
-    for bad in ([(0, 0, W + 1, 8)], [(0, 0, 0, 8)], [(0, 0, W, H), (0, 0, 8, 8)]):
+    # overlapping tiles are refused whatever their total area (two threads would own one pixel's sums)
+    for bad in ([(0, 0, W + 1, 8)], [(0, 0, 0, 8)], [(0, 0, W, H), (0, 0, 8, 8)], [(0, 0, 16, 16), (8, 8, 16, 16)],
+                [(40, 0, 8, 8), (0, 0, 8, 8), (4, 7, 8, 8)]):
         with pytest.raises(Exception):
             r.render_tiles_device(a, c, p, sc.camera, bad, spp=1)
 
@@ -316,6 +318,60 @@ def test_march_shortcut_does_not_change_the_image(monkeypatch):
     for a, b in zip(*frames):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert (frames[0][1].sum(-1) > 0).any()
+
+
+def test_samples_call_in_several_passes(monkeypatch):
+    """PTMI_CHUNK_MSAMPLES bounds the samples of one pass over a region; the per-sample output of ptmi_render_samples
+    is laid out over the whole sample range, so it always takes one pass, and the accumulating calls add their passes
+    up to the same sums (2 M samples against a 1 M-sample bound)."""
+    from pathtrace_amd import Context
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    p = make_params(128, 128, bounces=2, seed=12)
+    out = []
+    for chunk in (None, "1"):
+        if chunk is None:
+            monkeypatch.delenv("PTMI_CHUNK_MSAMPLES", raising=False)
+        else:
+            monkeypatch.setenv("PTMI_CHUNK_MSAMPLES", chunk)
+        ctx = Context(0)
+        try:
+            r = Renderer(sc, ctx=ctx)
+            smp = r.render_samples(p, sc.camera, spp=128)
+            fb = r.new_framebuffer(128, 128)
+            r.render_tile(fb, p, sc.camera, spp=128)
+            out.append((smp, fb.accum.copy(), fb.counts.copy()))
+        finally:
+            ctx.close()
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2]) and (out[0][2] == 128).all()
+    # and the sums are the samples added in order
+    acc = np.zeros((128, 128, 3), np.float32)
+    for s_ in range(128):
+        acc += out[0][0][:, :, s_]
+    assert np.array_equal(acc, out[0][1])
+
+
+def test_new_bvh_invalidates_the_scene():
+    """A new tree replaces the mesh the scene's per-triangle records were built for: render calls report
+    PTMI_ERR_NO_SCENE until the scene is uploaded again (they must not read the old, smaller buffers)."""
+    from pathtrace_amd import PtmiError, Context, BuildBVH, ConstructLinearBVH
+    ctx = Context(0)
+    try:
+        small = scenes.bunny_scene(small=True)
+        r = Renderer(small, ctx=ctx)
+        p = make_params(32, 32, seed=3)
+        before = r.render_samples(p, small.camera, spp=1)
+        big = scenes.bunny_scene(small=False, glass=True, emissive=True)
+        ConstructLinearBVH(BuildBVH(big.verts, big.tris), ctx=ctx)          # same context, larger mesh, no scene upload
+        with pytest.raises(PtmiError) as e:
+            r.render_samples(p, small.camera, spp=1)
+        assert e.value.code == -6
+        r2 = Renderer(big, ctx=ctx)                                          # uploading the scene makes it renderable again
+        assert np.isfinite(r2.render_samples(p, big.camera, spp=1)).all()
+        r3 = Renderer(small, ctx=ctx)
+        assert np.array_equal(r3.render_samples(p, small.camera, spp=1), before)
+    finally:
+        ctx.close()
 
 
 def test_render_errors(gpu_ctx):

@@ -102,6 +102,44 @@ def test_upload_prebuilt_tree_and_errors(gpu_ctx):
     fresh.close()
 
 
+def test_dev_calls_overlapping_on_two_streams(gpu_ctx):
+    """ptmi_closest_hit_dev / ptmi_any_hit_dev are asynchronous on caller-chosen streams, so launches of one context can
+    overlap on the device: each launch has a ray cursor of its own (a ring of counter lines), and every result equals the
+    oracle's.  Several rounds of closest-hit on stream A against any-hit (and a second closest-hit batch) on stream B,
+    both non-blocking streams, nothing synchronised in between."""
+    import torch
+    v, f = scenes.make_soup(200_000, seed=31)
+    box = BuildBVH(v, f)
+    bvh = ConstructLinearBVH(box, ctx=gpu_ctx)
+    orc = oracle_lib.OracleBVH(v, f, linear=box.linear())
+    dev = torch.device("cuda", 0)
+    n = 1 << 20
+    oa, da = random_rays(v, n, 71)
+    ob, db = random_rays(v, n // 2, 72)
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    OA, DA, OB, DB = (torch.from_numpy(x).to(dev) for x in (oa, da, ob, db))
+    TA = torch.full((n,), 1000.0, dtype=torch.float32, device=dev); TB = torch.full((n // 2,), 1000.0, dtype=torch.float32, device=dev)
+    rounds = 4
+    PA = [torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(rounds)]
+    tA = [torch.full((n,), -7.0, dtype=torch.float32, device=dev) for _ in range(rounds)]
+    OCC = [torch.full((n // 2,), 9, dtype=torch.uint8, device=dev) for _ in range(rounds)]
+    PB = [torch.full((n // 2,), -7, dtype=torch.int32, device=dev) for _ in range(rounds)]
+    tB = [torch.full((n // 2,), -7.0, dtype=torch.float32, device=dev) for _ in range(rounds)]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        bvh.CheckIntersectionDevice(OA, DA, TA, PA[r], tA[r], sa.cuda_stream)
+        bvh.QuickCheckIntersectionDevice(OB, DB, TB, OCC[r], sb.cuda_stream)
+        bvh.CheckIntersectionDevice(OB, DB, TB, PB[r], tB[r], sb.cuda_stream)
+    torch.cuda.synchronize()
+    pa, ta, _ = orc.closest_hit(oa, da, 1000.0, counters=False)
+    pb, tb, _ = orc.closest_hit(ob, db, 1000.0, counters=False)
+    occ, _ = orc.any_hit(ob, db, 1000.0, counters=False)
+    for r in range(rounds):
+        assert np.array_equal(PA[r].cpu().numpy(), pa) and bits_equal(tA[r].cpu().numpy(), ta), f"round {r}: stream A"
+        assert np.array_equal(PB[r].cpu().numpy(), pb) and bits_equal(tB[r].cpu().numpy(), tb), f"round {r}: stream B closest"
+        assert np.array_equal(OCC[r].cpu().numpy().astype(bool), occ), f"round {r}: stream B any-hit"
+
+
 import glob
 import os
 
