@@ -113,6 +113,17 @@ int ptmi_closest_hit(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, cons
 int ptmi_closest_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax,
                          uint64_t n, int32_t *prim_id, float *t, void *stream);
 
+/* No counterpart in the reference.  ptmi_closest_hit_dev for callers that cannot allocate device memory: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same kernels, same
+ * results bit for bit; the one piece of scratch the persistent kernel needs (its ray cursor) lives in a 256-byte
+ * __device__ array of the library instead of the context's hipMalloc'd block, and the call makes no hipMalloc /
+ * hipFree: one hipMemsetAsync of that array and one kernel launch on `stream`.  n may be at most
+ * PTMI_NOALLOC_MAX_RAYS; a larger n returns PTMI_ERR_INVALID.  Every call on a GPU uses that GPU's one array
+ * (whatever the context or stream): calls that overlap on one GPU race -- order them on one stream or with events. */
+#define PTMI_NOALLOC_MAX_RAYS (1ull << 32)
+int ptmi_closest_hit_dev_noalloc(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax,
+                                 uint64_t n, int32_t *prim_id, float *t, void *stream);
+
 /* Replaces (*LinearBVH).QuickCheckIntersection (linear_bvh.go:202-250): occluded[n] = 1 if any
  * triangle is hit in (1e-5, tmax). */
 int ptmi_any_hit(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "ptmi_bvh_stats": (C.c_int, [_P, C.POINTER(PtBvhStats)]),
     "ptmi_closest_hit": (C.c_int, [_P, _F, _F, _F, _U64, _I32, _F]),
     "ptmi_closest_hit_dev": (C.c_int, [_P, _P, _P, _P, _U64, _P, _P, _P]),
+    "ptmi_closest_hit_dev_noalloc": (C.c_int, [_P, _P, _P, _P, _U64, _P, _P, _P]),
     "ptmi_any_hit": (C.c_int, [_P, _F, _F, _F, _U64, _U8]),
     "ptmi_any_hit_dev": (C.c_int, [_P, _P, _P, _P, _U64, _P, _P]),
     "ptmi_set_counting": (C.c_int, [_P, C.c_int]),

@@ -167,6 +167,14 @@ class LinearBVH:
         check(self._lib.ptmi_closest_hit_dev(self.ctx.handle, o.data_ptr(), d.data_ptr(), step.data_ptr(), n,
                                              prim.data_ptr(), t.data_ptr(), s), self.ctx.handle)
 
+    def CheckIntersectionDeviceNoAlloc(self, o, d, step, prim, t, stream=None, n=None):
+        """ptmi_closest_hit_dev_noalloc: the same query without any device allocation (static scratch in the library);
+        calls on one GPU must not overlap."""
+        n = o.shape[0] if n is None else n
+        s = C.c_void_p(stream) if stream else None
+        check(self._lib.ptmi_closest_hit_dev_noalloc(self.ctx.handle, o.data_ptr(), d.data_ptr(), step.data_ptr(), n,
+                                                     prim.data_ptr(), t.data_ptr(), s), self.ctx.handle)
+
     def QuickCheckIntersectionDevice(self, o, d, step, occ, stream=None):
         n = o.shape[0]
         s = C.c_void_p(stream) if stream else None

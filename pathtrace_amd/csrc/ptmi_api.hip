@@ -190,6 +190,19 @@ static int launch_connect(ptmi_ctx *ctx, const LaunchScratch &sc, const float *o
     return PTMI_OK;
 }
 
+// ------------------------------------------------------------------------------------ allocation-free scratch
+// ptmi_closest_hit_dev_noalloc (no counterpart in the reference) serves callers that cannot allocate: code under HIP
+// graph capture, tight serving loops, harnesses that forbid hipMalloc.  The persistent extend kernel needs one piece of
+// device memory beyond its inputs and outputs -- the ray cursor its waves draw chunks from, which the ordinary entry
+// points keep in the hipMalloc'd counter block of the context.  Here it lives in this file-scope array: one 128-byte
+// line for the cursor (atomics on one line serialise, so it shares its line with nothing), padded to the array's
+// 256-byte alignment.  The size does not depend on the number of rays.  In host code `scratch` is only a stand-in for the
+// symbol: ptmi_create asks the runtime for the array's address on the context's device and every use goes through
+// that pointer (ctx->noalloc_scratch).  All calls on one GPU share the array: calls that overlap on one GPU race.
+constexpr size_t NOALLOC_SCRATCH_WORDS = 2 * CNT_WORDS;          // 256 bytes
+constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_SCRATCH_WORDS * sizeof(unsigned long long);
+static __device__ __align__(256) unsigned long long scratch[NOALLOC_SCRATCH_WORDS];
+
 // ------------------------------------------------------------------------------------ context
 
 extern "C" const char *ptmi_version(void) { return "ptmi 0.1 (gfx950)"; }
@@ -235,6 +248,16 @@ extern "C" int ptmi_create(int device, ptmi_ctx **out) {
         set_err(nullptr, PTMI_ERR_HIP, std::string("ptmi_create: ") + hipGetErrorString(e));
         delete ctx;
         return PTMI_ERR_HIP;
+    }
+    {   // address of the allocation-free entry point's scratch on THIS device (the device is current: hipSetDevice above)
+        unsigned long long *ptr = nullptr;
+        if ((e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch))) != hipSuccess || !ptr ||
+            (e = hipMemset(ptr, 0, NOALLOC_SCRATCH_BYTES)) != hipSuccess) {
+            set_err(nullptr, PTMI_ERR_HIP, std::string("ptmi_create: hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+            ptmi_destroy(ctx);
+            return PTMI_ERR_HIP;
+        }
+        ctx->noalloc_scratch = ptr;
     }
     *out = ctx;
     return PTMI_OK;
@@ -495,6 +518,29 @@ extern "C" int ptmi_closest_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const flo
     if (!o_xyz || !d_xyz || !tmax || !prim_id || !t) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_closest_hit_dev: null buffer");
     PTMI_HIP(ctx, hipSetDevice(ctx->device));
     return dispatch_extend(ctx, ctx_scratch(ctx), o_xyz, d_xyz, tmax, n, prim_id, t, (hipStream_t)stream);
+}
+
+// Allocation-free form of ptmi_closest_hit_dev: the same kernels, the ray cursor in the static scratch array.  Calls no
+// hipMalloc / hipFree (nor any routine that does): a memset of the scratch and one kernel launch on `stream`.
+extern "C" int ptmi_closest_hit_dev_noalloc(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax,
+                                            uint64_t n, int32_t *prim_id, float *t, void *stream) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_closest_hit_dev_noalloc: ctx is null");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_closest_hit_dev_noalloc: no BVH uploaded");
+    if (n > (uint64_t)PTMI_NOALLOC_MAX_RAYS)
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_closest_hit_dev_noalloc: " + std::to_string(n) + " rays in one call, the maximum is " +
+                                              std::to_string((uint64_t)PTMI_NOALLOC_MAX_RAYS) + " (PTMI_NOALLOC_MAX_RAYS)");
+    if (n == 0) return PTMI_OK;
+    if (!o_xyz || !d_xyz || !tmax || !prim_id || !t) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_closest_hit_dev_noalloc: null buffer");
+    if (!ctx->noalloc_scratch) return set_err(ctx, PTMI_ERR_HIP, "ptmi_closest_hit_dev_noalloc: scratch address not resolved");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    // the array keeps the last call's contents: the whole of it starts every call at zero (the launchers clear the
+    // cursor word again, as they do for the ring)
+    PTMI_HIP(ctx, hipMemsetAsync(ctx->noalloc_scratch, 0, NOALLOC_SCRATCH_BYTES, s));
+    // work counting selects kernels that add to the context's hipMalloc'd counter block, which is still valid memory
+    // here (allocated at ptmi_create); only the cursor moves into the scratch
+    const LaunchScratch sc{ctx->d_counters, ctx->noalloc_scratch};
+    return dispatch_extend(ctx, sc, o_xyz, d_xyz, tmax, n, prim_id, t, s);
 }
 
 extern "C" int ptmi_any_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n,

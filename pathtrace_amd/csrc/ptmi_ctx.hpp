@@ -96,6 +96,10 @@ struct ptmi_ctx {
 
     float tight_min[3] = {0, 0, 0}, tight_max[3] = {0, 0, 0}, tight_margin = 0.0f;   // see DevBVH
     uint32_t tight_valid = 0;
+    // the allocation-free entry point's scratch on this context's device: the address of ptmi_api.hip's file-scope
+    // __device__ array, resolved once in ptmi_create with this device current (every GPU has its own copy)
+    unsigned long long *noalloc_scratch = nullptr;
+
     ptmi::DevBVH dev_bvh() const {
         return ptmi::DevBVH{d_nodes, d_tris, root_ref, bounds_finite, dummy_tri,
                             {tight_min[0], tight_min[1], tight_min[2]}, {tight_max[0], tight_max[1], tight_max[2]}, tight_margin, tight_valid};
