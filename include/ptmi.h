@@ -44,7 +44,8 @@ enum {
     PTMI_ERR_NO_BVH = -4,      /* query before ptmi_build_bvh / ptmi_upload_bvh               */
     PTMI_ERR_DEPTH = -5,       /* tree deeper than the traversal stack (reference: 64 entries) */
     PTMI_ERR_NO_SCENE = -6,    /* ptmi_render before ptmi_upload_scene                         */
-    PTMI_ERR_OOM = -7
+    PTMI_ERR_OOM = -7,
+    PTMI_ERR_COMM = -8         /* RCCL unavailable or a collective failed; text in ptmi_last_error */
 };
 
 /* ------------------------------------------------------------------ context */
@@ -265,6 +266,47 @@ int ptmi_render_samples(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *p
  * column 0 never written, as in the reference).  rgba: width*height*4 bytes, host, caller-initialised. */
 int ptmi_to_rgba(ptmi_ctx *ctx, const float *accum_rgb, const uint32_t *counts, int32_t width, int32_t height,
                  uint8_t *rgba);
+
+/* ------------------------------------------------------------------ multi-GPU (RCCL over xGMI) */
+
+/* No counterpart in the reference: its tile workers are goroutines of one process that write disjoint Pixels of one
+ * shared buffer (main.go:472-491 sets the tiles up, :935-937 starts one worker per tile, :878 / :896 are the
+ * unsynchronised writes).  Across GPUs the same disjoint regions are put together by ONE collective per frame: every
+ * GPU adds its share into a zero-initialised full-frame accumulator and an RCCL reduce (sum) puts the frame on
+ * `root`; the regions are disjoint, so the reduced sums equal a single-GPU render bit for bit.  BVH and scene are
+ * replicated (ptmi_build_bvh / ptmi_upload_scene on every context).  RCCL is loaded when the first of these calls
+ * is made (librccl.so of the process or of the ROCm installation; PTMI_RCCL_LIB overrides); without it they return
+ * PTMI_ERR_COMM and everything else keeps working.
+ *
+ * One communicator per context.  Either one process (or thread) per GPU: rank 0 calls ptmi_comm_unique_id, hands
+ * the 128 bytes to the other ranks by whatever channel the host has, and EVERY rank calls ptmi_comm_init_rank
+ * (collective).  Or one process driving all GPUs of a node (a Go host: one goroutine per GPU):
+ * ptmi_comm_init_all(ctxs, n) makes ctxs[i] rank i.  Collectives are enqueued on `stream` and must be called by all
+ * ranks in the same order; with several contexts in one process call them from one thread per context (a collective
+ * returns once every rank has joined it). */
+#define PTMI_UNIQUE_ID_BYTES 128
+int ptmi_comm_unique_id(uint8_t id[PTMI_UNIQUE_ID_BYTES]);
+int ptmi_comm_init_rank(ptmi_ctx *ctx, int nranks, int rank, const uint8_t id[PTMI_UNIQUE_ID_BYTES]);
+int ptmi_comm_init_all(ptmi_ctx **ctxs, int n);
+int ptmi_comm_rank(const ptmi_ctx *ctx, int *rank, int *nranks);     /* (0, 1) without a communicator */
+int ptmi_comm_destroy(ptmi_ctx *ctx);                                /* also done by ptmi_destroy */
+
+/* Sum of all ranks' full-frame device buffers onto `root` (ncclReduce, float32 sums + uint32 counts in one group):
+ * recv_* are only written on root and may equal send_* (in place).  A context without a communicator is a world of
+ * one: the call copies (or does nothing in place).  Replaces the shared-memory Pixel buffer of main.go:878. */
+int ptmi_reduce_frame(ptmi_ctx *ctx, const float *send_accum, const uint32_t *send_counts, float *recv_accum,
+                      uint32_t *recv_counts, int32_t width, int32_t height, int root, void *stream);
+
+/* A whole frame over all ranks in one call per rank -- the multi-GPU form of the `calculate` workers
+ * (main.go:832-899, :935-937): clears the full-frame device buffers, renders this rank's rows (ptmi_render_rows_dev
+ * with shard = rank, nshards = nranks: rows y with (y / row_block) % nranks == rank) for samples
+ * [spp_begin, spp_begin + spp_count), and reduces onto `root`, whose buffers then hold the frame -- bit-identical to
+ * ptmi_render_dev of the whole frame into zeroed buffers on one GPU.  To continue a frame over several calls keep
+ * per-rank buffers with ptmi_render_rows_dev and reduce once with ptmi_reduce_frame (out of place).  If a rank's
+ * render fails it returns the error without joining the reduce: the host must then tear the job down. */
+int ptmi_render_sharded(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t row_block,
+                        uint32_t spp_begin, uint32_t spp_count, float *accum_rgb, uint32_t *counts, int root,
+                        void *stream);
 
 /* ------------------------------------------------------------------ assets (host only) */
 

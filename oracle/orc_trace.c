@@ -24,9 +24,12 @@
  *     reproducible offline).
  *   - textures / bump maps (renderer.go:88-291) are not restated yet.
  */
+#define _POSIX_C_SOURCE 200809L
 #include "orc_bvh.h"
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define PI32 ((float)3.14159265358979323846)
 
@@ -761,6 +764,60 @@ void orc_render(const orc_scene *sc, const float *cam, const orc_params *p, int 
         c0 += cnt.closest; c1 += cnt.any; c2 += cnt.diffuse_events; c3 += cnt.samples;
     }
     if (counters) { counters[0] += c0; counters[1] += c1; counters[2] += c2; counters[3] += c3; }
+}
+
+/* The goroutine tile renderer itself (main.go:435, :454-491, :832-899, :935-937), for the CPU baseline: the image is
+ * split into splits_x x splits_y tiles of (W / splits_x) x (H / splits_y) pixels (main.go:454-457, :474-482; pixels beyond
+ * the last full tile are not rendered, as in the reference) and ONE worker thread is started per tile -- the reference's
+ * threadCount goroutines, which cover the image only when threadCount == splitsX * splitsY.  A worker walks its tile in
+ * the effective schedule of GetNoisiestPixel at the committed constants (row-major, every pixel picked once and given
+ * `spp` samples: tile.go:34-66 with samplesPerPixel == maxSamplesPerPixel) and adds the samples as
+ * Pixel.AddSample does.  accum_rgb / counts are full frames [H][W].  Returns the wall-clock seconds from starting the
+ * workers to joining the last one (the reference times nothing else either: main.go:935-937 -> :904). */
+typedef struct { const orc_scene *sc; const float *cam; const orc_params *p; int x0, y0, w, h; uint32_t spp;
+                 float *accum; uint32_t *counts; orc_trace_counters cnt; } tile_job;
+static void *tile_worker(void *arg) {
+    tile_job *j = (tile_job *)arg;
+    memset(&j->cnt, 0, sizeof j->cnt);
+    const int W = j->p->width;
+    for (int y = 0; y < j->h; ++y)
+        for (int x = 0; x < j->w; ++x) {
+            const int X = j->x0 + x, Y = j->y0 + y;
+            const size_t i = (size_t)Y * W + X;
+            for (uint32_t s = 0; s < j->spp; ++s) {                                          /* main.go:861-879 */
+                v3 c = sample_pixel(j->sc, j->p, j->cam, X, Y, s, &j->cnt);
+                j->accum[3 * i] += c.x; j->accum[3 * i + 1] += c.y; j->accum[3 * i + 2] += c.z;
+                j->counts[i] += 1;
+            }
+        }
+    return NULL;
+}
+double orc_render_tile_workers(const orc_scene *sc, const float *cam, const orc_params *p, int splits_x, int splits_y,
+                               uint32_t spp, float *accum_rgb, uint32_t *counts, uint64_t *counters) {
+    if (splits_x < 1 || splits_y < 1) return -1.0;
+    const int nt = splits_x * splits_y, tw = p->width / splits_x, th = p->height / splits_y;
+    tile_job *jobs = (tile_job *)calloc((size_t)nt, sizeof(tile_job));
+    pthread_t *thr = (pthread_t *)calloc((size_t)nt, sizeof(pthread_t));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int started = 0;
+    for (int i = 0; i < nt; ++i) {
+        tile_job *j = &jobs[i];
+        j->sc = sc; j->cam = cam; j->p = p; j->x0 = (i % splits_x) * tw; j->y0 = (i / splits_x) * th; j->w = tw; j->h = th;
+        j->spp = spp; j->accum = accum_rgb; j->counts = counts;
+        if (pthread_create(&thr[i], NULL, tile_worker, j) != 0) break;
+        ++started;
+    }
+    for (int i = 0; i < started; ++i) pthread_join(thr[i], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (counters)
+        for (int i = 0; i < started; ++i) {
+            counters[0] += jobs[i].cnt.closest; counters[1] += jobs[i].cnt.any; counters[2] += jobs[i].cnt.diffuse_events;
+            counters[3] += jobs[i].cnt.samples;
+        }
+    free(jobs); free(thr);
+    if (started != nt) return -1.0;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
 /* Per-sample radiance (no accumulation), for debugging / fine-grained comparison: out[w*h*spp_count*3],

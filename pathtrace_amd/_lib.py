@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libptmi.so")
 
 PTMI_OK = 0
 ERR_NAMES = {-1: "PTMI_ERR_INVALID", -2: "PTMI_ERR_NO_DEVICE", -3: "PTMI_ERR_HIP", -4: "PTMI_ERR_NO_BVH",
-             -5: "PTMI_ERR_DEPTH", -6: "PTMI_ERR_NO_SCENE", -7: "PTMI_ERR_OOM"}
+             -5: "PTMI_ERR_DEPTH", -6: "PTMI_ERR_NO_SCENE", -7: "PTMI_ERR_OOM", -8: "PTMI_ERR_COMM"}
+UNIQUE_ID_BYTES = 128
 
 
 class PtmiError(RuntimeError):
@@ -91,6 +92,14 @@ SIGNATURES = {
     "ptmi_render_samples": (C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_uint32, C.c_uint32, _F]),
     "ptmi_to_rgba": (C.c_int, [_P, _F, _U32, C.c_int32, C.c_int32, _U8]),
+    "ptmi_comm_unique_id": (C.c_int, [_U8]),
+    "ptmi_comm_init_rank": (C.c_int, [_P, C.c_int, C.c_int, _U8]),
+    "ptmi_comm_init_all": (C.c_int, [C.POINTER(_P), C.c_int]),
+    "ptmi_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ptmi_comm_destroy": (C.c_int, [_P]),
+    "ptmi_reduce_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int, _P]),
+    "ptmi_render_sharded": (C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), C.c_int32, C.c_uint32, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ptmi_obj_load": (C.c_int, [C.c_char_p, C.c_float, _F, C.POINTER(C.c_void_p)]),
     "ptmi_obj_free": (None, [_P]),
     "ptmi_obj_last_error": (C.c_char_p, []),

@@ -276,6 +276,7 @@ extern "C" void ptmi_destroy(ptmi_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    (void)ptmi_comm_destroy(ctx);
     free_bvh_device(ctx);
     ptmi::free_scene(ctx);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);

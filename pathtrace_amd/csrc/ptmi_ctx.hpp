@@ -96,6 +96,10 @@ struct ptmi_ctx {
 
     float tight_min[3] = {0, 0, 0}, tight_max[3] = {0, 0, 0}, tight_margin = 0.0f;   // see DevBVH
     uint32_t tight_valid = 0;
+    // RCCL communicator of this context (ptmi_comm.hip; an ncclComm_t), its rank and the number of ranks
+    void *comm = nullptr;
+    int comm_rank = 0, comm_nranks = 1;
+
     // the allocation-free entry point's scratch on this context's device: the address of ptmi_api.hip's file-scope
     // __device__ array, resolved once in ptmi_create with this device current (every GPU has its own copy)
     unsigned long long *noalloc_scratch = nullptr;

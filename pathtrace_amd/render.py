@@ -132,6 +132,18 @@ class Renderer:
         check(self._lib.ptmi_render_rows_dev(self.ctx.handle, C.byref(cam), C.byref(params), row_block, shard, nshards,
                                              spp_begin, spp, accum.data_ptr(), counts.data_ptr(), s), self.ctx.handle)
 
+    def render_sharded_device(self, accum, counts, params: PtParams, camera, row_block=8, spp=32, spp_begin=0, root=0,
+                              stream=None):
+        """ptmi_render_sharded: this rank's rows of the frame + the RCCL reduce onto `root`, in one call (the context's
+        communicator decides rank and world; without one it is a single-GPU frame).  FULL-FRAME torch CUDA tensors,
+        cleared by the call."""
+        cam = camera if isinstance(camera, PtCamera) else make_camera(camera)
+        assert tuple(accum.shape) == (params.height, params.width, 3) and accum.is_contiguous()
+        assert tuple(counts.shape) == (params.height, params.width) and counts.is_contiguous()
+        s = C.c_void_p(stream) if stream else None
+        check(self._lib.ptmi_render_sharded(self.ctx.handle, C.byref(cam), C.byref(params), row_block, spp_begin, spp,
+                                            accum.data_ptr(), counts.data_ptr(), root, s), self.ctx.handle)
+
     def render_tiles_device(self, accum, counts, params: PtParams, camera, tiles, spp=32, spp_begin=0, stream=None):
         """Several disjoint tiles [(x0, y0, w, h), ...] in one call, added into FULL-FRAME torch CUDA tensors."""
         cam = camera if isinstance(camera, PtCamera) else make_camera(camera)

@@ -6,8 +6,10 @@ it, so a 64x64 tile never fills the machine): `mode="rows"` deals blocks of `row
 (`(y // row_block) % world == rank`, rendered by ptmi_render_rows_dev in one pass); `mode="tile"` keeps the
 reference's granularity (`tile_id % world == rank`; all of a rank's tiles in one ptmi_render_tiles_dev call).  Every
 rank adds its share into a zero-initialised full-frame accumulator, which is then summed onto `dst` with one
-`torch.distributed.reduce` (backend "nccl" = RCCL over xGMI; 4K frame = 99.5 MB + 33 MB of counts).  Regions are
-disjoint, so the reduced sums are bit-identical to a single-GPU render (x + 0 == x).  RNG streams are keyed by
+reduce (RCCL over xGMI; 4K frame = 99.5 MB + 33 MB of counts).  The reduce is the library's own: `PtmiComm` wraps the
+C ABI's communicator (`ptmi_comm_init_rank`, `ptmi_reduce_frame`, `ptmi_render_sharded`: ncclReduce behind
+include/ptmi.h, what a Go host calls too); `DistComm` (torch.distributed) only serves the CPU tests (gloo) and the
+one-GPU rehearsal.  Regions are disjoint, so the reduced sums are bit-identical to a single-GPU render (x + 0 == x).  RNG streams are keyed by
 (pixel, sample), so the image does not depend on the number of ranks.  `mode="sample"` splits the sample range
 instead (for small frames): partial sums are then added in rank order, deterministic but not bit-identical to
 one GPU's sequential sum.
@@ -52,13 +54,101 @@ def merge_rects(rects):
     return out
 
 
+class DistComm:
+    """Framebuffer reduce over torch.distributed -- gloo on the CPU (tests) or any object with the same `reduce`
+    (bench.py's host-staged rehearsal).  The product's GPU path uses PtmiComm."""
+    kind = "dist"
+
+    def __init__(self, dist, rank, world, group=None):
+        self.dist, self.rank, self.world, self.group = dist, rank, world, group
+
+    def reduce_frame(self, accum, counts, root=0, stream=None):
+        if self.world > 1:
+            self.dist.reduce(accum, dst=root, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.dist.reduce(counts, dst=root, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def close(self):
+        pass
+
+
+class PtmiComm:
+    """The C ABI's RCCL communicator of a context (include/ptmi.h "multi-GPU"): one rank per process.  `unique_id` is
+    the 128 bytes rank 0 got from PtmiComm.unique_id(), handed over by any channel the host has."""
+    kind = "rccl"
+
+    def __init__(self, ctx, rank, world, unique_id: bytes):
+        import ctypes as C
+        from . import _lib
+        from ._lib import check
+        self._lib, self._check, self._C = _lib.load(), check, C
+        self.ctx, self.rank, self.world = ctx, rank, world
+        buf = (C.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        check(self._lib.ptmi_comm_init_rank(ctx.handle, world, rank, buf), ctx.handle)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        from ._lib import check
+        buf = (C.c_uint8 * _lib.UNIQUE_ID_BYTES)()
+        check(_lib.load().ptmi_comm_unique_id(buf))
+        return bytes(buf)
+
+    def reduce_frame(self, accum, counts, root=0, stream=None):
+        """In-place ncclReduce(sum) of FULL-FRAME torch CUDA tensors onto `root`, enqueued on `stream`."""
+        C = self._C
+        h, w = counts.shape
+        s = C.c_void_p(stream) if stream else None
+        self._check(self._lib.ptmi_reduce_frame(self.ctx.handle, accum.data_ptr(), counts.data_ptr(), accum.data_ptr(),
+                                                counts.data_ptr(), w, h, root, s), self.ctx.handle)
+
+    def close(self):
+        if self.ctx is not None and self.ctx.handle:
+            self._lib.ptmi_comm_destroy(self.ctx.handle)
+        self.ctx = None
+
+
+def make_comm(renderer, rank, world, dist, dev, rehearse=False):
+    """The communicator of this rank's context.  The RCCL unique id travels over the process group the launcher set up
+    (torch.distributed: a 128-byte broadcast); with rehearse=True (all ranks on one GPU, which RCCL refuses) the reduce
+    goes through the host instead."""
+    if world <= 1:
+        return None
+    if rehearse:
+        return DistComm(dist, rank, world)
+    import torch
+    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(PtmiComm.unique_id()), dtype=torch.uint8))
+    dist.broadcast(uid, src=0)
+    return PtmiComm(renderer.ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
+
+
+def render_frame_sharded(renderer, comm, accum, counts, params, camera, spp, row_block=8, root=0, stream=None, spp_begin=0):
+    """One frame over all ranks: this rank's rows into the cleared full-frame CUDA tensors, then the reduce onto
+    `root`.  With a PtmiComm (or no communicator) that is ONE C-ABI call, ptmi_render_sharded."""
+    if comm is None or comm.kind == "rccl":
+        renderer.render_sharded_device(accum, counts, params, camera, row_block=row_block, spp=spp, spp_begin=spp_begin,
+                                       root=root, stream=stream)
+        return accum, counts
+    accum.zero_()
+    counts.zero_()
+    renderer.render_rows_device(accum, counts, params, camera, shard=comm.rank, nshards=comm.world, row_block=row_block,
+                                spp=spp, spp_begin=spp_begin, stream=stream)
+    comm.reduce_frame(accum, counts, root, stream)
+    return accum, counts
+
+
 def render_sharded(render_rect, accum, counts, width, height, spp, rank=0, world=1, dist=None, dst=0, mode="tile",
-                   tile=64, group=None, render_rows=None, row_block=8, render_tiles=None):
+                   tile=64, group=None, render_rows=None, row_block=8, render_tiles=None, comm=None, stream=None):
     """Render this rank's shard with `render_rect(rect, spp_begin, spp)` (which must ADD into the rows/cols of the
-    full-frame tensors `accum` [H,W,3] / `counts` [H,W] it is given views of) and reduce onto `dst`.
+    full-frame tensors `accum` [H,W,3] / `counts` [H,W] it is given views of) and reduce onto `dst` through `comm`
+    (PtmiComm on GPUs; `dist=` wraps a torch.distributed module in a DistComm for the CPU tests).
 
     render_rect(accum_view, counts_view, rect, spp_begin, spp_count) -> None
     """
+    if comm is None and dist is not None and world > 1:
+        comm = DistComm(dist, rank, world, group)
     accum.zero_()
     counts.zero_()
     if mode == "tile":
@@ -80,9 +170,8 @@ def render_sharded(render_rect, accum, counts, width, height, spp, rank=0, world
             render_rect(accum, counts, (0, 0, width, height), b, n)
     else:
         raise ValueError(mode)
-    if dist is not None and world > 1:
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
-        dist.reduce(counts, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    if comm is not None and world > 1:
+        comm.reduce_frame(accum, counts, dst, stream)
     return accum, counts
 
 

@@ -182,6 +182,8 @@ def _load_trace():
     lib.orc_render_samples.restype = None
     lib.orc_render_samples.argtypes = [C.c_void_p, _F, C.POINTER(OrcParams), C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_uint32, C.c_uint32, _F, C.c_int]
+    lib.orc_render_tile_workers.restype = C.c_double
+    lib.orc_render_tile_workers.argtypes = [C.c_void_p, _F, C.POINTER(OrcParams), C.c_int, C.c_int, C.c_uint32, _F, _U32, _U64P]
     lib.orc_to_rgba.restype = None
     lib.orc_to_rgba.argtypes = [_F, _U32, C.c_int, C.c_int, _U8]
     lib._trace_ready = True
@@ -242,6 +244,19 @@ class OracleScene:
                             _p(accum, C.c_float), _p(counts, C.c_uint32), _p(cnt, C.c_uint64), nthreads)
         return accum, counts, dict(closest=int(cnt[0]), any=int(cnt[1]), diffuse_events=int(cnt[2]),
                                    samples=int(cnt[3]))
+
+    def render_tile_workers(self, cam, params, splits=(4, 4), spp=16):
+        """The goroutine tile renderer (main.go:435, :454-491, :832-899): one worker thread per tile.  Returns
+        (accum [H,W,3], counts [H,W], counters, wall seconds of the render loop)."""
+        cam = np.ascontiguousarray(cam, np.float32)
+        accum = np.zeros((params.height, params.width, 3), np.float32)
+        counts = np.zeros((params.height, params.width), np.uint32)
+        cnt = np.zeros(4, np.uint64)
+        secs = self.lib.orc_render_tile_workers(self.h, _p(cam, C.c_float), C.byref(params), int(splits[0]), int(splits[1]),
+                                                int(spp), _p(accum, C.c_float), _p(counts, C.c_uint32), _p(cnt, C.c_uint64))
+        if secs < 0:
+            raise RuntimeError("orc_render_tile_workers: could not start the workers")
+        return accum, counts, dict(closest=int(cnt[0]), any=int(cnt[1]), diffuse_events=int(cnt[2]), samples=int(cnt[3])), secs
 
     def render_samples(self, cam, params, rect=None, spp_begin=0, spp_count=1, nthreads=8):
         x0, y0, w, h = rect or (0, 0, params.width, params.height)

@@ -197,3 +197,18 @@ def test_transform_normal_identity_fallback_and_frame():
     assert np.allclose(tbn([0, 1, 0], wn, tri, [0.25] * 6), [-1, 0, 0], atol=1e-6)
     got = tbn([0.6, 0, 0.8], wn, tri, [0, 0, 1, 0, 0, 1])
     assert np.allclose(got, [0.6, 0.8, 0], atol=1e-6) and abs(np.linalg.norm(got) - 1) < 1e-6
+
+
+def test_tile_worker_renderer_equals_the_pixel_loop():
+    """The CPU baseline's goroutine-style tile renderer (one thread per tile, main.go:454-491, :832-899) adds the same
+    samples in the same order as the OpenMP pixel loop the parity tests use: identical sums, full coverage when the
+    splits divide the image, uncovered remainder otherwise (as in the reference)."""
+    from pathtrace_amd import scenes
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    osc = oracle_lib.OracleScene(sc)
+    p = osc.params(48, 40, bounces=2, seed=3)
+    acc, cnt, oc = osc.render(sc.camera.as_array(), p, spp_count=3)
+    acc2, cnt2, oc2, secs = osc.render_tile_workers(sc.camera.as_array(), p, splits=(4, 4), spp=3)
+    assert secs > 0 and np.array_equal(acc, acc2) and np.array_equal(cnt, cnt2) and oc == oc2
+    acc3, cnt3, _, _ = osc.render_tile_workers(sc.camera.as_array(), p, splits=(5, 3), spp=2)      # 48/5 = 9, 40/3 = 13
+    assert (cnt3[:39, :45] == 2).all() and (cnt3[39:] == 0).all() and (cnt3[:, 45:] == 0).all()

@@ -175,6 +175,55 @@ def test_row_shards_sum_to_the_frame(gpu_ctx):
         r.render_rows_device(ref, refc, p, sc.camera, shard=2, nshards=2)
 
 
+def test_comm_and_sharded_render_through_the_c_abi():
+    """ptmi_comm_* / ptmi_reduce_frame / ptmi_render_sharded (RCCL behind the C ABI) in a world of one -- all this box
+    has: the communicator is created from a unique id, ptmi_render_sharded gives the single-call frame bit for bit
+    (and clears what the buffers held), the reduce copies out of place, and the same calls work without a
+    communicator.  The world > 1 host logic runs under gloo in tests/test_sharded_cpu.py."""
+    import ctypes as C
+    import torch
+    from pathtrace_amd import Context, _lib
+    lib = _lib.load()
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    W, H, spp = 72, 53, 3
+    p = make_params(W, H, bounces=2, seed=5)
+    dev = torch.device("cuda", 0)
+    ctx = Context(0)
+    try:
+        r = Renderer(sc, ctx=ctx)
+        ref = torch.zeros((H, W, 3), dtype=torch.float32, device=dev); refc = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        r.render_device(ref, refc, p, sc.camera, spp=spp)
+        rank, world = C.c_int(-1), C.c_int(-1)
+        assert lib.ptmi_comm_rank(ctx.handle, C.byref(rank), C.byref(world)) == 0 and (rank.value, world.value) == (0, 1)
+        for with_comm in (False, True, "all"):
+            comm = None
+            if with_comm is True:
+                comm = sharded.PtmiComm(ctx, 0, 1, sharded.PtmiComm.unique_id())
+            elif with_comm == "all":
+                arr = (C.c_void_p * 1)(ctx.handle)
+                assert lib.ptmi_comm_init_all(arr, 1) == 0, lib.ptmi_last_error(ctx.handle)
+            assert lib.ptmi_comm_rank(ctx.handle, C.byref(rank), C.byref(world)) == 0 and (rank.value, world.value) == (0, 1)
+            a = torch.full((H, W, 3), 7.0, dtype=torch.float32, device=dev); c = torch.full((H, W), 7, dtype=torch.int32, device=dev)
+            sharded.render_frame_sharded(r, comm, a, c, p, sc.camera, spp, row_block=8, root=0,
+                                         stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(a, ref) and torch.equal(c, refc)
+            # out-of-place reduce onto the root = a copy in a world of one
+            a2 = torch.zeros_like(a); c2 = torch.zeros_like(c)
+            rc = lib.ptmi_reduce_frame(ctx.handle, a.data_ptr(), c.data_ptr(), a2.data_ptr(), c2.data_ptr(), W, H, 0, None)
+            assert rc == 0, lib.ptmi_last_error(ctx.handle)
+            torch.cuda.synchronize()
+            assert torch.equal(a2, ref) and torch.equal(c2, refc)
+            assert lib.ptmi_reduce_frame(ctx.handle, a.data_ptr(), c.data_ptr(), a2.data_ptr(), c2.data_ptr(), W, H, 1, None) == -1   # root out of range
+            if comm is not None:
+                comm.close()
+            else:
+                assert lib.ptmi_comm_destroy(ctx.handle) == 0
+        assert lib.ptmi_comm_init_rank(ctx.handle, 2, 2, (C.c_uint8 * 128)()) == -1
+    finally:
+        ctx.close()
+
+
 def test_tiles_in_one_call(gpu_ctx):
     """ptmi_render_tiles_dev: a list of tiles rendered in one wavefront pass gives the sums of one call per tile."""
     import torch

@@ -85,3 +85,69 @@ def test_reduce_matches_single_process(mode):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok == (True, True)
+
+
+class _FakeRenderer:
+    """Stands in for render.Renderer: only the call render_frame_sharded makes without an RCCL communicator."""
+
+    def render_rows_device(self, accum, counts, params, camera, shard=0, nshards=1, row_block=8, spp=32, spp_begin=0, stream=None):
+        _fake_render_rows(accum, counts, shard, nshards, row_block, spp_begin, spp)
+
+    def render_sharded_device(self, *a, **k):
+        raise AssertionError("the C-ABI RCCL path needs a GPU: the CPU test must go through the stub communicator")
+
+
+def _frame_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H, spp = 96, 83, 4
+    a = torch.full((H, W, 3), 5.0); c = torch.full((H, W), 5, dtype=torch.int32)        # stale contents must be cleared
+    comm = sharded.make_comm(None, rank, world, dist, None, rehearse=True)           # the gloo stub of the communicator
+    assert comm.kind == "dist" and (comm.rank, comm.world) == (rank, world)
+    sharded.render_frame_sharded(_FakeRenderer(), comm, a, c, None, None, spp, row_block=8, root=0)
+    if rank == 0:
+        ra, rc = _single(W, H, spp)
+        q.put((bool(torch.equal(a, ra)), bool(torch.equal(c, rc))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_render_frame_sharded_world_2_with_stub_comm():
+    """render_frame_sharded -- what bench.py's render leg and a multi-GPU host run -- with two ranks: the per-rank row
+    shards and one reduce through the communicator interface (PtmiComm on GPUs, the gloo stub here) give the frame."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_frame_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok == (True, True)
+
+
+def test_comm_entry_points_fail_cleanly_without_rccl():
+    """The comm entry points bind RCCL at run time; when it cannot be loaded they return PTMI_ERR_COMM with a reason,
+    and bad arguments are refused before that.  (A child process: the binding is made once per process.)"""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C\n"
+        "from pathtrace_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "assert lib.ptmi_comm_unique_id(None) == -1\n"
+        "assert lib.ptmi_comm_init_rank(None, 1, 0, None) == -1\n"
+        "assert lib.ptmi_comm_init_all(None, 0) == -1\n"
+        "assert lib.ptmi_reduce_frame(None, None, None, None, None, 4, 4, 0, None) == -1\n"
+        "buf = (C.c_uint8 * 128)()\n"
+        "rc = lib.ptmi_comm_unique_id(buf)\n"
+        "msg = lib.ptmi_last_error(None).decode()\n"
+        "assert rc == -8 and 'RCCL unavailable' in msg and '/nonexistent/librccl.so' in msg, (rc, msg)\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PTMI_RCCL_LIB="/nonexistent/librccl.so", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr
