@@ -66,3 +66,47 @@ def adversarial_rays(verts, tris, n, seed):
 def bits_equal(a, b):
     a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
     return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def write_obj_scene(dirpath, sc, name="scene", glass_materials=(), emissive=()):
+    """Writes a SceneData as an OBJ / MTL pair (+ binary PPM textures) the way the reference's assets look
+    (obj_loader.go:19-111 reads them): one object, `usemtl` groups, per-corner `vn` and `vt`, v stored as 1 - v (LoadObj
+    flips it back), floats with 9 significant digits so that float32 values survive the text.  Materials listed in
+    `glass_materials` get a name with the prefix "Glass" (tracer.go:49 detects glass by name)."""
+    import os
+    nt = sc.tris.shape[0]
+    names = [("Glass%d" % i) if i in glass_materials else ("mat%d" % i) for i in range(sc.materials.shape[0])]
+    tex_files = []
+    for i, t in enumerate(sc.textures or []):
+        fn = f"{name}_tex{i + 1}.ppm"
+        rgb = np.stack([t & 0xFF, (t >> 8) & 0xFF, (t >> 16) & 0xFF], -1).astype(np.uint8)
+        with open(os.path.join(dirpath, fn), "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (t.shape[1], t.shape[0]) + rgb.tobytes())
+        tex_files.append(fn)
+    mu = sc.materials.view(np.uint32)
+    with open(os.path.join(dirpath, name + ".mtl"), "w") as f:
+        for i, m in enumerate(sc.materials):
+            f.write(f"newmtl {names[i]}\nKd {m[0]:.9g} {m[1]:.9g} {m[2]:.9g}\nKs {m[3]:.9g} {m[4]:.9g} {m[5]:.9g}\n"
+                    f"Ke {m[6]:.9g} {m[7]:.9g} {m[8]:.9g}\nNi {m[9]:.9g}\nNs {m[10]:.9g}\nillum 2\n")
+            if mu[i, 12]:
+                f.write(f"map_Kd {tex_files[mu[i, 12] - 1]}\n")
+            if mu[i, 13]:
+                f.write(f"map_Bump {tex_files[mu[i, 13] - 1]}\n")
+    uvs = sc.uvs if sc.uvs is not None else np.zeros((nt, 6), np.float32)
+    with open(os.path.join(dirpath, name + ".obj"), "w") as f:
+        f.write(f"mtllib {name}.mtl\n")
+        for v in sc.verts:
+            f.write(f"v {v[0]:.9g} {v[1]:.9g} {v[2]:.9g}\n")
+        for n in sc.normals:
+            f.write(f"vn {n[0]:.9g} {n[1]:.9g} {n[2]:.9g}\n")
+        for uv in uvs.reshape(-1, 2):
+            f.write(f"vt {uv[0]:.9g} {np.float32(1.0) - uv[1]:.9g}\n")
+        f.write("o everything\n")
+        cur = -1
+        for t in range(nt):
+            if sc.tri_material[t] != cur:
+                cur = int(sc.tri_material[t])
+                f.write(f"usemtl {names[cur]}\n")
+            a, b, c = (int(x) + 1 for x in sc.tris[t])
+            f.write(f"f {a}/{3 * t + 1}/{3 * t + 1} {b}/{3 * t + 2}/{3 * t + 2} {c}/{3 * t + 3}/{3 * t + 3}\n")
+    return os.path.join(dirpath, name + ".obj")

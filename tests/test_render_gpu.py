@@ -117,6 +117,52 @@ def test_textures_and_bump_maps(gpu_ctx):
     assert np.array_equal(r.render_samples(p, sc.camera, spp=3), got_plain)
 
 
+def test_obj_asset_end_to_end(gpu_ctx, tmp_path):
+    """LoadObj -> DecomposeObjects -> BuildBVH -> TraceRay end to end (obj_loader.go:19-111, renderer.go:293-324,
+    main.go:784-810, :875): an OBJ / MTL pair with PPM textures, a glass material by NAME and an emissive one is
+    written to disk, parsed by the C ABI's loader (ptmi_obj_*), uploaded and rendered on the GPU; the oracle is fed the
+    arrays the loader returned and must agree per sample.  The loaded arrays are also checked against what was
+    written."""
+    from helpers import write_obj_scene
+    from pathtrace_amd.obj import LoadObj
+    src = scenes.textured_scene(small=True)
+    # a glass sphere and an emissive quad on top of the textured scene, as extra materials
+    gv, gf = scenes.icosphere(1)
+    gv = (gv * np.float32(0.5) + np.array([-1.6, 0.5, 1.2], np.float32)).astype(np.float32)
+    ev, ef = scenes.quad((-1.0, 3.2, -1.0), (1.0, 3.2, -1.0), (1.0, 3.2, 1.0), (-1.0, 3.2, 1.0))
+    nv = src.verts.shape[0]
+    src.verts = np.concatenate([src.verts, gv, ev]).astype(np.float32)
+    src.tris = np.concatenate([src.tris, gf + nv, ef + nv + gv.shape[0]]).astype(np.uint32)
+    src.normals = np.concatenate([src.normals, scenes.corner_normals_smooth(gv, gf), scenes.corner_normals_flat(ev, ef)]).astype(np.float32)
+    nm = src.materials.shape[0]
+    src.materials = np.concatenate([src.materials, scenes.material(kd=(0.9, 0.9, 0.9), ni=1.5)[None],
+                                    scenes.material(kd=(0, 0, 0), ke=(12.0, 11.0, 9.0))[None]]).astype(np.float32)
+    src.tri_material = np.concatenate([src.tri_material, np.full(gf.shape[0], nm, np.uint32), np.full(ef.shape[0], nm + 1, np.uint32)])
+    src.uvs = np.concatenate([src.uvs, np.zeros((gf.shape[0] + ef.shape[0], 6), np.float32)]).astype(np.float32)
+    path = write_obj_scene(str(tmp_path), src, glass_materials=(nm,))
+
+    sc = LoadObj(path, scale_factor=1.0)
+    assert sc.tris.shape == src.tris.shape and np.array_equal(sc.verts[sc.tris], src.verts[src.tris])      # same triangles
+    assert np.abs(sc.normals - src.normals).max() < 1e-6 and np.abs(sc.uvs - src.uvs).max() < 1e-6
+    assert sc.names[nm].startswith("Glass") and sc.materials.view(np.uint32)[nm, 11] == scenes.MAT_GLASS   # glass by name
+    assert np.array_equal(sc.materials[:, :11], src.materials[:, :11]) and np.array_equal(sc.tri_material, src.tri_material)
+    assert len(sc.textures) == 3 and sorted(t.shape for t in sc.textures) == sorted(t.shape for t in src.textures)
+    for t in sc.textures:                                           # PPM keeps RGB; CacheImage's alpha is 255
+        assert any(np.array_equal(t & 0xFFFFFF, u & 0xFFFFFF) for u in src.textures)
+    # an OBJ has no lights, sky or camera: the host adds them (main.go:509-541)
+    sc.lights, sc.sky, sc.camera = src.lights, src.sky, src.camera
+    p = make_params(64, 64, bounces=2, seed=7)
+    r, osc, got, want = _compare_samples(sc, p, 3, gpu_ctx)
+    assert (got.sum(-1) > 0).mean() > 0.9
+    # the glass name matters: the same file with the prefix removed renders differently
+    plain = write_obj_scene(str(tmp_path), src, name="plain", glass_materials=())
+    sc2 = LoadObj(plain)
+    sc2.lights, sc2.sky, sc2.camera = src.lights, src.sky, src.camera
+    assert sc2.materials.view(np.uint32)[nm, 11] == 0
+    got2 = Renderer(sc2, ctx=gpu_ctx).render_samples(p, sc2.camera, spp=3)
+    assert np.abs(got2 - got).mean() > 1e-4
+
+
 def test_accumulation_counts_rects_and_counters(gpu_ctx):
     sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
     p = make_params(64, 48, bounces=2, seed=21)
@@ -319,6 +365,91 @@ def test_full_size_frame_properties(gpu_ctx):
     band = a[536:544].cpu().numpy()
     rmse = np.sqrt(((band - acc) ** 2).mean()) / spp
     assert rmse <= IMAGE_RMSE_TOL * (acc / spp).mean(), (rmse, (acc / spp).mean())
+
+
+def test_full_size_c4_frame_properties():
+    """BASELINE.json configs[3] at full size: the 10.4 M-triangle C4 scene at 3840x2160 (2 spp: the properties do not
+    depend on the sample count), checked through properties that need no full CPU pass: a re-run is bit-identical, the
+    row shards of 2 and of 8 "ranks" sum to the whole frame bit for bit (what ptmi_render_sharded's reduce adds up),
+    every pixel got its samples, and the image agrees with the CPU oracle on a band of rows (per sample)."""
+    import torch
+    from pathtrace_amd import Context
+    sc = scenes.c4_scene()
+    assert sc.tris.shape[0] > 10_000_000
+    W, H, spp = 3840, 2160, 2
+    p = make_params(W, H, bounces=2, seed=1)
+    dev = torch.device("cuda", 0)
+    ctx = Context(0)                               # its own context: the 10 M-triangle tree and a 4K pool go away with it
+    try:
+        r = Renderer(sc, ctx=ctx)
+        assert r.box.GetStats().total_triangles == sc.tris.shape[0]
+
+        def frame():
+            return (torch.zeros((H, W, 3), dtype=torch.float32, device=dev), torch.zeros((H, W), dtype=torch.int32, device=dev))
+
+        a, c = frame(); r.render_device(a, c, p, sc.camera, spp=spp)
+        b, cb = frame(); r.render_device(b, cb, p, sc.camera, spp=spp)
+        assert torch.equal(a, b) and torch.equal(c, cb) and bool((c == spp).all())
+        assert bool(torch.isfinite(a).all()) and float(a.min()) >= 0.0 and float(a.mean()) > 0.05
+        for world in (2, 8):
+            tot, totc = frame()
+            for rank in range(world):
+                s_, sc_ = frame()
+                r.render_rows_device(s_, sc_, p, sc.camera, shard=rank, nshards=world, row_block=8, spp=spp)
+                tot += s_; totc += sc_
+            assert torch.equal(a, tot) and torch.equal(c, totc), f"{world} row shards do not sum to the frame"
+        # the oracle on rows 1076..1079 (through the blob, the glass sphere and the height field), per sample
+        rect = (0, 1076, W, 4)
+        got = r.render_samples(p, sc.camera, rect=rect, spp=spp)
+        osc = oracle_lib.OracleScene(sc, bvh=oracle_lib.OracleBVH(sc.verts, sc.tris, linear=r.box.linear()))
+        want = osc.render_samples(sc.camera.as_array(), _oparams(p), rect=rect, spp_count=spp, nthreads=16)
+        err = (np.abs(got - want) / (1.0 + np.abs(want))).max(-1)
+        assert (err > REL_TOL).mean() <= MAX_OUTLIER_FRACTION, f"{(err > REL_TOL).sum()} of {err.size} samples differ"
+        band = a[1076:1080].cpu().numpy()
+        assert np.array_equal(band, got[:, :, 0] + got[:, :, 1])          # Pixel.AddSample's sums: (0 + s0) + s1
+    finally:
+        ctx.close()
+
+
+def test_full_size_blackhole_frame_properties(monkeypatch):
+    """BASELINE.json configs[4] at full size: the black-hole scene at 3840x2160, maxSteps = 3000, stepSize = 1
+    (main.go:451-452), 1 spp: a re-run is bit-identical, the march's "segment outside the tree" shortcut does not change a
+    bit of the 4K frame, every pixel got its sample, the disk and the shadow are both in the picture, and a band of rows
+    through the disk equals the CPU oracle's RK4 march per sample."""
+    import torch
+    from pathtrace_amd import Context
+    sc = scenes.blackhole_scene()
+    W, H = 3840, 2160
+    p = make_params(W, H, bounces=1, max_steps=3000, step_size=1.0, seed=2)
+    dev = torch.device("cuda", 0)
+    frames = []
+    for shortcut in ("1", "0"):
+        monkeypatch.setenv("PTMI_SEGMENT_SHORTCUT", shortcut)
+        ctx = Context(0)
+        try:
+            r = Renderer(sc, ctx=ctx)
+            a = torch.zeros((H, W, 3), dtype=torch.float32, device=dev); c = torch.zeros((H, W), dtype=torch.int32, device=dev)
+            r.render_device(a, c, p, sc.camera, spp=1)
+            if shortcut == "1":
+                b = torch.zeros_like(a); cb = torch.zeros_like(c)
+                r.render_device(b, cb, p, sc.camera, spp=1)
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(c, cb)
+                rect = (0, H // 2 - 1, W, 2)
+                got = r.render_samples(p, sc.camera, rect=rect, spp=1)
+            frames.append((a.cpu(), c.cpu()))
+        finally:
+            ctx.close()
+    (a1, c1), (a0, c0) = frames
+    assert torch.equal(a1.view(torch.int32), a0.view(torch.int32)) and torch.equal(c1, c0) and bool((c1 == 1).all())
+    lum = a1.sum(-1)
+    assert float((lum > 0).float().mean()) > 0.02 and float((lum == 0).float().mean()) > 0.001      # disk / sky, and the shadow
+    osc = oracle_lib.OracleScene(sc)
+    want = osc.render_samples(sc.camera.as_array(), _oparams(p), rect=rect, spp_count=1, nthreads=16)
+    both = np.isfinite(want).all(-1) & np.isfinite(got).all(-1)
+    assert np.array_equal(np.isfinite(want), np.isfinite(got))
+    err = (np.abs(got - want) / (1.0 + np.abs(want))).max(-1)
+    assert ((err > REL_TOL) & both).mean() <= MAX_OUTLIER_FRACTION, f"{((err > REL_TOL) & both).sum()} of {err.size} samples differ"
+    assert np.array_equal(a1[H // 2 - 1: H // 2 + 1].numpy().view(np.uint32), got[:, :, 0].view(np.uint32))
 
 
 def test_frame_loop_writes_frames(gpu_ctx, tmp_path):
