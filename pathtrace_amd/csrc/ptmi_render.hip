@@ -36,8 +36,10 @@ enum {
     F_BOUNCES = 0, F_BINDEX = 1, F_FLAGS = 2, F_ENERGY = 3, F_LN = 4,      // inputs of TraceRay (:15)
     F_RO = 7, F_RD = 10, F_T = 13, F_PRIM = 14,                            // the hit being shaded
     F_DG = 15, F_DIFF = 16,                                                // doppler*gravity, diffuse component
-    F_REFR = 19, F_DIRECT = 22, F_SUM = 25, F_S = 28, F_PHASE = 29, F_NEED = 30,
-    NF = 31, FRW = 32
+    F_REFR = 19, F_ALBEDO = 22, F_SUM = 25, F_S = 28, F_PHASE = 29, F_NEED = 30, F_MAT = 31,
+    // F_ALBEDO / F_MAT: what HandleDiffuseMaterial's final sum needs of the hit (textured albedo, material), kept in the
+    // frame so that a frame popped by a returning child does not gather its triangle record again
+    NF = 32, FRW = 32
 };
 enum { FL_SPECULAR = 1, FL_FLIPPED = 2 };
 // what the top frame is waiting for
@@ -57,17 +59,21 @@ struct ShadowCounts { uint32_t n[NSB]; };
 // entries cannot overflow.  The counters follow the queue counters (one memset clears both).
 enum { RETRY_SHARDS = 256, BAIL_MAX = 16 };
 enum { QC_CURSOR = QC_COUNT + RETRY_SHARDS, QC_CURSOR_EXT = QC_CURSOR + 1 };     // ray cursors of the vote-scheduled kernels
-// Path header, 32 words = one 128-byte line per slot (8 x float4):
-//   q0  sample id, RNG key, RNG counter, packed (depth | tracker length << 8 | HP_PENDING)
-//   q1  tracker entry 0, hit status, hit primitive, hit t            (words 1-3 are written by extend)
-//   q2  V_t at the start of the geodesic, V_t now (written by extend)   q3  -   (the current ray lives in the extend queue entry)
-//   q4  arguments of the pending TraceRay call: bounces, bounceIndex, flags, energy     q5  lastSurfaceNormal
-//   q6, q7  tracker entries 1-8 (deeper histories continue in Pool::trk)
-// HP_PENDING: the top of the recursion stack is a TraceRay call that has not looked at its hit yet.  Such a
-// frame has no contents beyond its arguments, so it lives in the header and frame memory is only touched when a
-// frame is parked under a child or waits for its shadow rays; a fresh sample is a pending call at depth 0.
-enum { HQ = 8, HW_TRK1 = 24, HDR_TRK = 8 };
-constexpr uint32_t HP_PENDING = 0x80000000u;
+// Path state that travels with the queues (no per-path header in memory):
+//   extend queue entry i = the pending TraceRay call of a path, three coalesced arrays per queue buffer:
+//     q_ext_ray[2i], [2i+1]  (o.xyz, bits(slot)) / (d.xyz, V_t at the start of the geodesic -- curved rays only)
+//     q_ext_arg[3i..3i+2]    (sample id, RNG key, RNG counter, depth | tracker length << 8)
+//                            (bounces, bounceIndex, flags, energy)           -- the arguments of the call (tracer.go:15)
+//                            (lastSurfaceNormal.xyz, tracker entry 0)
+//     q_ext_hit[i]           (hit status, primitive, t, V_t now)             -- written by extend
+//   shadow-wait queue entry = a parked frame waiting for connect's answers, 2 x float4:
+//     (bits(slot), sample id, RNG key, RNG counter) / (depth | tracker length << 8, tracker entry 0, -, -)
+// A pending call has no state beyond its arguments, so a fresh sample and a pushed child touch no per-path memory at
+// all: shade reads them from the queue (coalesced), extend answers into the queue, and frame memory is only touched
+// when a frame is parked under a child or waits for its shadow rays.  (Round 1 kept this state in a 128-byte header
+// line per path: 80 bytes read and 64 written per visit, scattered, plus extend's 12-byte partial-line write.)
+// Tracker entries beyond the first live in Pool::trk and are only touched by glass hits.
+enum { QA = 3 };
 
 // self-check failures reported through counters[CNT_ERROR] (a corrupted path is dropped, never dereferenced)
 enum { ERR_SLOT = 1, ERR_DEPTH = 2, ERR_PRIM = 4, ERR_MAT = 8, ERR_PHASE = 16 };
@@ -100,13 +106,14 @@ struct RenderArgs {
 struct Pool {
     uint32_t cap;
     int nframes, ntrk, nshadow;          // bounces+1, tracker history capacity (multiple of 4), nlights+2
-    float4 *hdr;                         // [cap][HQ]           header
     float4 *fr;                          // [cap][nframes][8]   frames (F_*)
-    float *trk;                          // [cap][ntrk]         RefractiveIndexTracker.indices
+    float *trk;                          // [cap][ntrk]         RefractiveIndexTracker.indices 1 .. (entry 0 travels with the path)
     float4 *sh;                          // [cap][nframes][nshadow]  (contribution.xyz, occluded as u32 bits) per frame
     // queues
-    float4 *q_ext_ray[2];                // extend queue (double buffered), 2 x float4 per entry: (o.xyz, bits(slot)) / (d.xyz, -)
-    uint32_t *q_shpath[2];               // paths waiting for their shadow rays
+    float4 *q_ext_ray[2];                // extend queue (double buffered), 2 x float4 per entry: (o.xyz, bits(slot)) / (d.xyz, V_t0)
+    float4 *q_ext_arg[2];                // ... its pending-call state, QA x float4 per entry
+    float4 *q_ext_hit;                   // ... extend's answer, one float4 per entry of the queue being traced
+    float4 *q_shpath[2];                 // paths waiting for their shadow rays, 2 x float4 per entry
     float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, bits(index into sh))
     uint32_t *q_retry; uint32_t retry_shard_cap;   // shadow rays a connect wave gave up on (RETRY_SHARDS regions), see connect
     uint32_t *q_free;                    // slots that finished in the last shade pass
@@ -155,64 +162,39 @@ __device__ __forceinline__ void region_pixel(const RenderArgs &ra, uint32_t pix,
 // main.go:861-874 + the TraceRay call of :875 (bounceIndex 0, lastSurfaceNormal {}, not specular,
 // NewRefractiveIndexTracker(1.0), energy 1.0)
 // Every generated path goes to the extend queue, so its queue position needs no atomic: entry q_base + i.
+// A fresh sample is a pending call and nothing else: one ray entry and one argument entry, both written coalesced.
 __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, const uint32_t *slots, uint32_t n,
-                                                       uint64_t first_sample, float4 *q_ray_next, uint32_t q_base) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = i < n;
-    uint32_t slot = 0;
-    V3 gen_o = mk(0, 0, 0), gen_d = mk(0, 0, 0);
-    uint32_t g_sid = 0, g_key = 0, g_ctr = 0;
-    if (live) {
-        slot = slots ? slots[i] : i;
-        const uint32_t sid = (uint32_t)first_sample + i;                   // total < 2^32/3 (render_core)
-        uint32_t pix = sid / ra.spp_chunk, s = sid % ra.spp_chunk;
-        int X, Y;
-        region_pixel(ra, pix, X, Y);
-        Rng rng = rng_init(ra.p.seed, (uint32_t)(Y * ra.p.width + X), ra.spp_begin + s);
-        float rx = ((float)X + rng_f32(rng)) / (float)ra.p.width;
-        float ry = ((float)Y + rng_f32(rng)) / (float)ra.p.height;
-        float px = (rx - 0.5f) * 2.0f, py = (ry - 0.5f) * 2.0f;
-        V3 pos = mk(ra.cam.position), fwd = mk(ra.cam.forward), right = mk(ra.cam.right), up = mk(ra.cam.up);
-        V3 rayOrigin = add(add(add(pos, scale(fwd, ra.cam.frustum_distance)), scale(up, py)), scale(right, px));
-        V3 d = normalize(mk(rayOrigin.x - pos.x, rayOrigin.y - pos.y, rayOrigin.z - pos.z));
-        gen_o = pos; gen_d = d;
-        g_sid = sid; g_key = rng.key; g_ctr = rng.ctr;
-    }
-    // A fresh sample is a header and nothing else (see HP_PENDING).  8 neighbouring lanes store one path's 128-byte
-    // header, so a store instruction carries whole lines (scattered 128-byte records: 5.3 TB/s against 3.2 TB/s
-    // when every lane writes its own record 16 bytes at a time -- tools/ubench_scatter.hip).
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t dead = 0xFFFFFFFFu;
-    const uint32_t my = live ? slot : dead;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {                                      // 8 lanes per header, 8 paths per instruction
-        const int src = j * 8 + (int)(lane >> 3);
-        const uint32_t q = lane & 7u;
-        const uint32_t ps = __shfl(my, src);
-        const uint32_t a0 = __shfl(g_sid, src), a1 = __shfl(g_key, src), a2 = __shfl(g_ctr, src);
-        const float dx = __shfl(gen_d.x, src), dy = __shfl(gen_d.y, src), dz = __shfl(gen_d.z, src);
-        const float ox = __shfl(gen_o.x, src), oy = __shfl(gen_o.y, src), oz = __shfl(gen_o.z, src);
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (q == 0) v = make_float4(u2f(a0), u2f(a1), u2f(a2), u2f(HP_PENDING | (1u << 8)));   // depth 0, tracker {1.0}
-        else if (q == 1) v = make_float4(1.0f, i2f(HS_MISS), i2f(-1), 0.0f);
-        else if (q == 2) v = make_float4(1.0f, 1.0f, ox, oy);
-        else if (q == 3) v = make_float4(oz, dx, dy, dz);
-        else if (q == 4) v = make_float4(i2f(ra.p.bounces), i2f(0), u2f(0u), 1.0f);             // main.go:875
-        if (ps != dead) pl.hdr[(size_t)ps * HQ + q] = v;
-    }
+                                                       uint64_t first_sample, float4 *q_ray_next, float4 *q_arg_next, uint32_t q_base) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = slots ? slots[i] : i;
+    const uint32_t sid = (uint32_t)first_sample + i;                       // total < 2^32/3 (render_core)
+    const uint32_t pix = sid / ra.spp_chunk, smp = sid % ra.spp_chunk;
+    int X, Y;
+    region_pixel(ra, pix, X, Y);
+    Rng rng = rng_init(ra.p.seed, (uint32_t)(Y * ra.p.width + X), ra.spp_begin + smp);
+    const float rx = ((float)X + rng_f32(rng)) / (float)ra.p.width;
+    const float ry = ((float)Y + rng_f32(rng)) / (float)ra.p.height;
+    const float px = (rx - 0.5f) * 2.0f, py = (ry - 0.5f) * 2.0f;
+    const V3 pos = mk(ra.cam.position), fwd = mk(ra.cam.forward), right = mk(ra.cam.right), up = mk(ra.cam.up);
+    const V3 rayOrigin = add(add(add(pos, scale(fwd, ra.cam.frustum_distance)), scale(up, py)), scale(right, px));
+    const V3 d = normalize(mk(rayOrigin.x - pos.x, rayOrigin.y - pos.y, rayOrigin.z - pos.z));
+    const size_t e = (size_t)q_base + i;
+    float4 *qr = q_ray_next + 2 * e;
+    qr[0] = make_float4(pos.x, pos.y, pos.z, u2f(slot));
+    qr[1] = make_float4(d.x, d.y, d.z, 1.0f);
     // TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0; shade handles that case
-    if (live) {
-        float4 *qr = q_ray_next + 2 * (size_t)(q_base + i);
-        qr[0] = make_float4(gen_o.x, gen_o.y, gen_o.z, u2f(slot));
-        qr[1] = make_float4(gen_d.x, gen_d.y, gen_d.z, 0.0f);
-    }
+    float4 *qa = q_arg_next + QA * e;
+    qa[0] = make_float4(u2f(sid), u2f(rng.key), u2f(rng.ctr), u2f(0u | (1u << 8)));           // depth 0, tracker {1.0}
+    qa[1] = make_float4(i2f(ra.p.bounces), i2f(0), u2f(0u), 1.0f);                            // main.go:875
+    qa[2] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);                                              // lastSurfaceNormal {}, NewRefractiveIndexTracker(1.0)
 }
 
 // ------------------------------------------------------------------------------------------ extend
 // The march loop of TraceRay (tracer.go:33-35, 226-256): closest hit on the segment [0, stepSize];
 // on a miss advance (straight) or RK4-step the geodesic (curved) and test the horizon.
-// Queue entries carry the ray, so the kernel reads them coalesced and never reads the (scattered) path header;
-// it writes the hit into the header, and the ray back into its queue entry only when the march moved it.
+// Queue entries carry the ray and the answer goes into the queue's hit array, so the kernel touches no per-path memory;
+// it writes the ray back into its entry only when shade needs the moved one (a hit after marching, a curved ray).
 template <int STACK, bool CURVED>
 __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl, DevScene sc, RenderArgs ra,
                                                              float4 *__restrict__ qray, uint32_t n,
@@ -222,9 +204,6 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
     uint32_t nq = 0;
     if (i < n) {
         const float4 qa = qray[2 * (size_t)i], qb = qray[2 * (size_t)i + 1];
-        uint32_t slot = f2u(qa.w);
-        if (slot >= pl.cap) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT); slot = 0; }
-        float4 *hd = pl.hdr + (size_t)slot * HQ;
         V3 o = mk(qa.x, qa.y, qa.z);
         V3 d = mk(qb.x, qb.y, qb.z);
         RayState st = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -251,48 +230,40 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
                 if (dot(rel, rel) <= sc.bh.rs * sc.bh.rs) { status = HS_HORIZON; break; }   // :250-255
             }
         }
-        float *h1 = (float *)(hd + 1);                                             // word 0 (tracker length) is shade's
-        h1[1] = i2f(status); h1[2] = i2f(prim); h1[3] = t;
-        if (CURVED || moved) {               // shade reads the ray from this entry (same index in its list)
+        pl.q_ext_hit[i] = make_float4(i2f(status), i2f(prim), t, CURVED ? st.vt : 1.0f);
+        // shade reads the ray from this entry (same index in its list): the origin of a hit (tracer.go:37 adds t to
+        // the CURRENT origin) and, for a curved ray, the direction it ended with (the sky lookup of a miss, :260-263)
+        if (CURVED || (moved && status == HS_HIT)) {
             qray[2 * (size_t)i] = make_float4(o.x, o.y, o.z, qa.w);
-            qray[2 * (size_t)i + 1] = make_float4(d.x, d.y, d.z, 0.0f);
+            qray[2 * (size_t)i + 1] = make_float4(d.x, d.y, d.z, vt0);
         }
-        if (CURVED) { float *h2 = (float *)(hd + 2); h2[0] = vt0; h2[1] = st.vt; }
     }
     for (int off = 32; off > 0; off >>= 1) nq += __shfl_xor(nq, off);
     if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)nq);
 }
 
 // extend for straight rays with one segment per call (max_steps == 1, no black hole): persistent waves walking
-// vote-scheduled single steps (vote_walk, trav_device.hpp), queue entries dealt in chunks from one cursor.  Same outputs
-// as render_extend_kernel: the hit into the path header, the advanced ray (tracer.go:226-228) back into the entry on a miss.
-struct ExtendTag { uint32_t entry; float slot; };      // the slot word of the entry, kept as the bits it was read as
+// vote-scheduled single steps (vote_walk, trav_device.hpp), queue entries dealt in chunks from one cursor.  Same output
+// as render_extend_kernel: the answer into the queue's hit array (a ray that is traced once never moves before a hit,
+// and shade does not look at the origin of a miss, so the entry itself is never written back).
 template <int STACK>
-__global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Pool pl, RenderArgs ra, float4 *__restrict__ qray,
+__global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Pool pl, RenderArgs ra, const float4 *__restrict__ qray,
                                                                   uint32_t n, unsigned long long *cursor,
                                                                   unsigned long long *counters, int refill_min, int tri_bias,
                                                                   uint32_t chunk_rays) {
     __shared__ uint32_t smem[STACK * WAVE];
     const float step = ra.p.step_size;
     TravCounters cnt;
-    vote_walk<WAVE, false, false, ExtendTag>(
+    vote_walk<WAVE, false, false, uint32_t>(
         bvh, smem + threadIdx.x, n, cursor, refill_min, tri_bias, chunk_rays, cnt,
-        [&](uint64_t idx, NextRay &nx, ExtendTag &tag) {
+        [&](uint64_t idx, NextRay &nx, uint32_t &entry) {
             const float4 qa = qray[2 * (size_t)idx], qb = qray[2 * (size_t)idx + 1];
-            tag.entry = (uint32_t)idx; tag.slot = qa.w;
+            entry = (uint32_t)idx;
             nx.ox = qa.x; nx.oy = qa.y; nx.oz = qa.z; nx.dx = qb.x; nx.dy = qb.y; nx.dz = qb.z; nx.tmax = step;
         },
-        [&](const ExtendTag &tag, const RayTrav &r) {
-            uint32_t slot = f2u(tag.slot);
-            if (slot >= pl.cap) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT); slot = 0; }
-            float *h1 = (float *)(pl.hdr + (size_t)slot * HQ + 1);                 // word 0 (tracker entry 0) is shade's
+        [&](uint32_t entry, const RayTrav &r) {
             const bool hit = r.best >= 0;
-            h1[1] = i2f(hit ? HS_HIT : HS_MISS); h1[2] = i2f(r.best); h1[3] = hit ? r.best_t : 0.0f;
-            if (!hit) {                                                            // :226-228, as render_extend_kernel
-                const V3 o = add(mk(r.ox, r.oy, r.oz), scale(mk(r.dx, r.dy, r.dz), step));
-                qray[2 * (size_t)tag.entry] = make_float4(o.x, o.y, o.z, tag.slot);
-                qray[2 * (size_t)tag.entry + 1] = make_float4(r.dx, r.dy, r.dz, 0.0f);
-            }
+            pl.q_ext_hit[entry] = make_float4(i2f(hit ? HS_HIT : HS_MISS), i2f(r.best), hit ? r.best_t : 0.0f, 1.0f);
         });
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)n);
 }
@@ -409,9 +380,11 @@ __device__ __forceinline__ bool is_emissive(const PtMaterial &m) { return m.ke[0
 // States of the per-path machine inside one shade invocation.
 enum { ST_EXTENDED, ST_MATERIAL, ST_SHADOW_DONE, ST_GI_LOOP, ST_REFL_LOOP, ST_DIFFUSE_FINAL, ST_COMBINE, ST_RETURN };
 
+// list_a = the extend queue just traced (entries 0 .. na-1: ray, pending-call state, extend's answer, all read
+// coalesced), list_b = the shadow-wait queue (nb parked frames whose shadow rays connect has answered).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, const float4 *list_a,
-                                                    uint32_t na, const uint32_t *list_b, uint32_t nb,
-                                                    float4 *q_ray_next, uint32_t *q_shpath_next,
+                                                    const float4 *list_a_arg, uint32_t na, const float4 *list_b, uint32_t nb,
+                                                    float4 *q_ray_next, float4 *q_arg_next, float4 *q_shpath_next,
                                                     unsigned long long *qc_ext_next, unsigned long long *qc_shp_next,
                                                     unsigned long long *counters) {
     __shared__ float s_fw[FRW * 256];
@@ -429,31 +402,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     int stage_depth = 0;                       // depth of the frame that cast them (its shadow slots take the answers)
     uint32_t diffuse_events = 0;
     V3 out_o = mk(0, 0, 0), out_d = mk(0, 0, 0);   // the ray of a path that wants an extend (goes into its queue entry)
+    float4 out_a0 = make_float4(0, 0, 0, 0), out_a1 = out_a0, out_a2 = out_a0;   // ... and its pending-call state
     if (live) {
-        // list_a = the extend queue's entries (ray + slot) in the order extend answered them, list_b = slots
-        float4 qa = make_float4(0, 0, 0, 0), qb = qa;
-        if (i < na) { qa = list_a[2 * (size_t)i]; qb = list_a[2 * (size_t)i + 1]; slot = f2u(qa.w); }
-        else slot = list_b[i - na];
+        const bool pending = i < na;                                        // the extend list holds exactly the pending calls
+        float4 qa = make_float4(0, 0, 0, 0), qb = qa, a0, a1 = qa, a2, hq = qa;
+        if (pending) {
+            qa = list_a[2 * (size_t)i]; qb = list_a[2 * (size_t)i + 1];
+            a0 = list_a_arg[QA * (size_t)i]; a1 = list_a_arg[QA * (size_t)i + 1]; a2 = list_a_arg[QA * (size_t)i + 2];
+            hq = pl.q_ext_hit[i];
+            slot = f2u(qa.w);
+        } else {
+            const float4 e0 = list_b[2 * (size_t)(i - na)], e1 = list_b[2 * (size_t)(i - na) + 1];
+            slot = f2u(e0.x);
+            a0 = make_float4(e0.y, e0.z, e0.w, e1.x);
+            a2 = make_float4(0.0f, 0.0f, 0.0f, e1.y);
+        }
         uint32_t err = 0;
         if (slot >= pl.cap) { err = ERR_SLOT; slot = 0; }
-        float4 *hd = pl.hdr + (size_t)slot * HQ;
-        const float4 h0 = hd[0], h1 = hd[1], h2 = hd[2], h4 = hd[4], h5 = hd[5];
-        const uint32_t sid = f2u(h0.x);
-        Rng rng; rng.key = f2u(h0.y); rng.ctr = f2u(h0.z);
-        const uint32_t packed = f2u(h0.w);
+        const uint32_t sid = f2u(a0.x);
+        Rng rng; rng.key = f2u(a0.y); rng.ctr = f2u(a0.z);
+        const uint32_t packed = f2u(a0.w);
         int depth = (int)(packed & 0xFFu);
         if (depth >= pl.nframes) { err |= ERR_DEPTH; depth = 0; }
         uint32_t trk_len = (packed >> 8) & 0xFFu;
         if ((int)trk_len > pl.ntrk) { err |= ERR_DEPTH; trk_len = 0; }
-        const bool pending = (packed & HP_PENDING) != 0;
-        if (pending != (i < na)) err |= ERR_PHASE;                          // the extend list holds exactly the pending calls
-        float trk0 = h1.x;
-        const int hs = f2i(h1.y), hprim = f2i(h1.z);
-        const float ht = h1.w, vt0 = h2.x, vt1 = h2.y;
+        float trk0 = a2.w;
+        const int hs = f2i(hq.x), hprim = f2i(hq.y);
+        const float ht = hq.z, vt0 = qb.w, vt1 = hq.w;
         V3 cur_o = mk(qa.x, qa.y, qa.z), cur_d = mk(qb.x, qb.y, qb.z);      // the path's current ray (pending calls only)
-        float *hw = (float *)hd;
         float *trk = pl.trk + (size_t)slot * pl.ntrk;
-        // arguments of a child call pushed in this invocation (they go into the header when the path parks)
+        // arguments of a child call pushed in this invocation (they go into its queue entry when the path parks)
         int arg_bounces = 0, arg_bindex = 0; uint32_t arg_flags = 0; float arg_energy = 0.0f; V3 arg_ln = mk(0, 0, 0);
         float4 *frames = pl.fr + (size_t)slot * pl.nframes * 8;
         // shadow slots of the frame at depth `dep`
@@ -479,11 +457,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #define FU(field) f2u(FW(field))
 #define FI_SET(field, v) (FW(field) = i2f(v))
 #define FU_SET(field, v) (FW(field) = u2f(v))
-        // RefractiveIndexTracker.indices: entry 0 in a register (header), 1-8 in the header line, the rest in Pool::trk
-        auto trk_get = [&](uint32_t e) -> float { return e == 0 ? trk0 : e <= (uint32_t)HDR_TRK ? hw[HW_TRK1 + e - 1] : trk[e - 1 - HDR_TRK]; };
-        auto trk_set = [&](uint32_t e, float v) {
-            if (e == 0) trk0 = v; else if (e <= (uint32_t)HDR_TRK) hw[HW_TRK1 + e - 1] = v; else trk[e - 1 - HDR_TRK] = v;
-        };
+        // RefractiveIndexTracker.indices: entry 0 in a register (it travels with the path), the rest in Pool::trk
+        auto trk_get = [&](uint32_t e) -> float { return e == 0 ? trk0 : trk[e - 1]; };
+        auto trk_set = [&](uint32_t e, float v) { if (e == 0) trk0 = v; else trk[e - 1] = v; };
         auto trk_current = [&]() -> float { return trk_len == 0 ? 1.0f : trk_get(trk_len - 1); };
         auto trk_previous = [&]() -> float { return trk_len < 2 ? 1.0f : trk_get(trk_len - 2); };
 
@@ -519,13 +495,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         bool have_hit = false;
         // entry: a pending call starts from its arguments, a parked frame comes back with its shadow answers
         if (pending) {
-            FW(F_BOUNCES) = h4.x; FW(F_BINDEX) = h4.y; FW(F_FLAGS) = h4.z; FW(F_ENERGY) = h4.w;
-            FW(F_LN) = h5.x; FW(F_LN + 1) = h5.y; FW(F_LN + 2) = h5.z;
+            FW(F_BOUNCES) = a1.x; FW(F_BINDEX) = a1.y; FW(F_FLAGS) = a1.z; FW(F_ENERGY) = a1.w;
+            FW(F_LN) = a2.x; FW(F_LN + 1) = a2.y; FW(F_LN + 2) = a2.z;
             FU_SET(F_PHASE, PH_EXTEND);
             state = ST_EXTENDED;
         } else {
             load_frame(depth);
-            if (FU(F_PHASE) == PH_SHADOW_WAIT) { load_hit(h); have_hit = true; state = ST_SHADOW_DONE; }
+            if (FU(F_PHASE) == PH_SHADOW_WAIT) state = ST_SHADOW_DONE;
             else { err |= ERR_PHASE; state = ST_RETURN; depth = 0; }
         }
         for (;;) {
@@ -547,6 +523,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 FW(F_T) = ht; FI_SET(F_PRIM, hprim);
                 FU_SET(F_FLAGS, FU(F_FLAGS) & ~(uint32_t)FL_FLIPPED);
                 load_hit(h); have_hit = true;
+                FV_SET(F_ALBEDO, h.albedo); FU_SET(F_MAT, h.mat);
                 const PtMaterial &m = sc.mats[h.mat];
                 // doppler / gravitational factors and the disk colour depend only on this hit (:93-113)
                 float dg = 1.0f;
@@ -695,9 +672,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 state = FI(F_BOUNCES) > 0 ? ST_GI_LOOP : ST_DIFFUSE_FINAL; continue;
             }
             if (state == ST_GI_LOOP) {                                                              // :636-647
-                if (!have_hit) { load_hit(h); have_hit = true; }
                 const int s = FI(F_S);
                 if (s < ra.p.scatter_rays) {
+                    if (!have_hit) { load_hit(h); have_hit = true; }
                     V3 t1, t2; tangent_frame(h.dnormal, t1, t2);
                     V3 dir = cosine_sample2(rng, h.dnormal, t1, t2);
                     // bounces > 0 and the energy is this frame's own (already >= 1e-2): the child always runs
@@ -710,11 +687,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 state = ST_DIFFUSE_FINAL; continue;
             }
             if (state == ST_DIFFUSE_FINAL) {                                                        // :658-667
-                if (!have_hit) { load_hit(h); have_hit = true; }
-                const PtMaterial &m = sc.mats[h.mat];
+                uint32_t fmat = FU(F_MAT);
+                if (fmat >= sc.nmats) { err |= ERR_MAT; fmat = 0; }
+                const PtMaterial &m = sc.mats[fmat];
                 V3 indirect = FI(F_BOUNCES) > 0 ? FV(F_SUM) : mk(0, 0, 0);
                 // direct lighting from the answers of this frame's shadow rays
-                const V3 albedo = h.albedo;
+                const V3 albedo = FV(F_ALBEDO);
                 const uint32_t need = FU(F_NEED);
                 const float4 *shp = shp_at(depth);
                 V3 direct = mk(0, 0, 0);
@@ -731,7 +709,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     direct = add(direct, cmul(albedo, term(1 + (int)li)));
                 if (sc.nemissive > 0) direct = add(direct, term(1 + (int)sc.nlights));   // :617
                 V3 fin = direct;
-                fin = add(fin, scale(h.albedo, ra.p.ambient));
+                fin = add(fin, scale(albedo, ra.p.ambient));
                 fin = add(fin, scale(indirect, 1.0f));
                 if (FI(F_BINDEX) == 0 && is_emissive(m)) fin = add(fin, mk(m.ke));
                 diffuse_events++;
@@ -740,11 +718,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 state = ST_COMBINE; continue;
             }
             if (state == ST_REFL_LOOP) {                                                            // :670-722
-                if (!have_hit) { load_hit(h); have_hit = true; }
-                const PtMaterial &m = sc.mats[h.mat];
+                uint32_t fmat = FU(F_MAT);
+                if (fmat >= sc.nmats) { err |= ERR_MAT; fmat = 0; }
+                const PtMaterial &m = sc.mats[fmat];
                 const int bounces = FI(F_BOUNCES);
                 bool pushed = false;
                 while (FI(F_S) < ra.p.scatter_rays) {
+                    if (!have_hit) { load_hit(h); have_hit = true; }
                     float roughness = 1.0f / (1.0f + m.ns / 100.0f);
                     float dp = dot(h.rd, h.normal);
                     V3 reflDir = normalize(sub(h.rd, scale(h.normal, 2.0f * dp)));
@@ -786,8 +766,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 FV_SET(F_REFR, scale(ret, FW(F_ENERGY)));
                 state = ST_MATERIAL;
             } else if (ph == PH_GI_WAIT) {                                                          // :640-645
-                load_hit(h); have_hit = true;
-                V3 c = cmul(ret, h.albedo);
+                V3 c = cmul(ret, FV(F_ALBEDO));
                 FV_SET(F_SUM, add(FV(F_SUM), c));
                 FI_SET(F_S, FI(F_S) + 1);
                 state = ST_GI_LOOP;
@@ -801,12 +780,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)err);
             want_extend = want_shadow = false; n_sray = 0; finished = true;
         }
-        if (!finished) {
-            hd[0] = make_float4(h0.x, h0.y, u2f(rng.ctr), u2f((uint32_t)depth | trk_len << 8 | (want_extend ? HP_PENDING : 0u)));
-            hd[1] = make_float4(trk0, h1.y, h1.z, h1.w);
+        if (!finished) {      // the state that travels with the path, for its next queue entry
+            out_a0 = make_float4(a0.x, a0.y, u2f(rng.ctr), u2f((uint32_t)depth | trk_len << 8));
+            out_a2 = make_float4(arg_ln.x, arg_ln.y, arg_ln.z, trk0);
             if (want_extend) {
-                hd[4] = make_float4(i2f(arg_bounces), i2f(arg_bindex), u2f(arg_flags), arg_energy);
-                hd[5] = make_float4(arg_ln.x, arg_ln.y, arg_ln.z, 0.0f);
+                out_a1 = make_float4(i2f(arg_bounces), i2f(arg_bindex), u2f(arg_flags), arg_energy);
                 out_o = cur_o; out_d = cur_d;
             }
         }
@@ -857,11 +835,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (lane == 0 && diffuse_events) atomicAdd(&counter_shard(counters)[CNT_DIFFUSE], (unsigned long long)diffuse_events);
         __syncthreads();
         if (want_extend) {
-            const uint32_t pe = s_q[0][wv] + (uint32_t)__popcll(m_ext & lt);
-            q_ray_next[2 * (size_t)pe] = make_float4(out_o.x, out_o.y, out_o.z, u2f(slot));
-            q_ray_next[2 * (size_t)pe + 1] = make_float4(out_d.x, out_d.y, out_d.z, 0.0f);
+            const size_t pe = s_q[0][wv] + (uint32_t)__popcll(m_ext & lt);
+            q_ray_next[2 * pe] = make_float4(out_o.x, out_o.y, out_o.z, u2f(slot));
+            q_ray_next[2 * pe + 1] = make_float4(out_d.x, out_d.y, out_d.z, 1.0f);
+            q_arg_next[QA * pe] = out_a0; q_arg_next[QA * pe + 1] = out_a1; q_arg_next[QA * pe + 2] = out_a2;
         }
-        if (want_shadow) q_shpath_next[s_q[1][wv] + (uint32_t)__popcll(m_shp & lt)] = slot;
+        if (want_shadow) {
+            const size_t ps = s_q[1][wv] + (uint32_t)__popcll(m_shp & lt);
+            q_shpath_next[2 * ps] = make_float4(u2f(slot), out_a0.x, out_a0.y, out_a0.z);
+            q_shpath_next[2 * ps + 1] = make_float4(out_a0.w, out_a2.w, 0.0f, 0.0f);
+        }
         if (finished) pl.q_free[s_q[2][wv] + (uint32_t)__popcll(m_fin & lt)] = slot;
         if (n_sray) {
             uint32_t pos_last = s_q[3 + NSB - 1][wv] + (incl - (uint32_t)__popc(last_bits));
@@ -1074,7 +1057,9 @@ static int tracker_words(int bounces) {
 // device bytes one path of the pool takes (records + its share of every queue)
 static uint64_t pool_bytes_per_path(int bounces, int nlights) {
     const uint64_t nframes = (uint64_t)bounces + 1, nshadow = (uint64_t)nlights + 2;
-    return 128 + 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 * nframes + 32) * nshadow + 4 * 3 + 32 * 2 + nshadow;
+    // frames + tracker history + shadow slots and shadow-ray queue + extend queue (ray, state: double buffered; answer) +
+    // shadow-wait queue (double buffered) + free list + retry share
+    return 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 * nframes + 32) * nshadow + (32 + 16 * QA) * 2 + 16 + 32 * 2 + 4 + nshadow;
 }
 
 static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
@@ -1086,17 +1071,18 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     const int nframes = bounces + 1, nshadow = (int)rs->nlights + 2;
     const int ntrk = tracker_words(bounces);
     const size_t c = cap;
-    struct Off { size_t hdr, fr, trk, sh, qs0, qs1, ra, rb, qr0, qr1, free_, cnt, retry; } of[2];
+    struct Off { size_t fr, trk, sh, qs0, qs1, ra, rb, qr0, qr1, qa0, qa1, qh, free_, cnt, retry; } of[2];
     // connect launches at most cap * nshadow / 64 + NSB waves
     const size_t retry_shard_cap = (((size_t)cap * nshadow / WAVE + NSB) / RETRY_SHARDS + 1) * BAIL_MAX;
     size_t off = 0;
     for (int l = 0; l < lanes; ++l) {
         Off &o = of[l];
-        o.hdr = carve(off, 128 * c); o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
+        o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
         o.sh = carve(off, 16 * c * nshadow * (size_t)nframes);
-        o.qs0 = carve(off, 4 * c); o.qs1 = carve(off, 4 * c);
+        o.qs0 = carve(off, 32 * c); o.qs1 = carve(off, 32 * c);
         o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow);
         o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
+        o.qa0 = carve(off, 16 * QA * c); o.qa1 = carve(off, 16 * QA * c); o.qh = carve(off, 16 * c);
         o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * (QC_COUNT + RETRY_SHARDS + 2) * QC_STRIDE);
         o.retry = carve(off, 4 * retry_shard_cap * RETRY_SHARDS);
     }
@@ -1111,10 +1097,12 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
         const Off &o = of[l];
         Pool p{};
         p.cap = cap; p.nframes = nframes; p.nshadow = nshadow; p.ntrk = ntrk;
-        p.hdr = (float4 *)(b + o.hdr); p.fr = (float4 *)(b + o.fr); p.trk = (float *)(b + o.trk);
+        p.fr = (float4 *)(b + o.fr); p.trk = (float *)(b + o.trk);
         p.sh = (float4 *)(b + o.sh);
         p.q_ext_ray[0] = (float4 *)(b + o.qr0); p.q_ext_ray[1] = (float4 *)(b + o.qr1);
-        p.q_shpath[0] = (uint32_t *)(b + o.qs0); p.q_shpath[1] = (uint32_t *)(b + o.qs1);
+        p.q_ext_arg[0] = (float4 *)(b + o.qa0); p.q_ext_arg[1] = (float4 *)(b + o.qa1);
+        p.q_ext_hit = (float4 *)(b + o.qh);
+        p.q_shpath[0] = (float4 *)(b + o.qs0); p.q_shpath[1] = (float4 *)(b + o.qs1);
         p.q_sray_a = (float4 *)(b + o.ra); p.q_sray_b = (float4 *)(b + o.rb);
         p.q_free = (uint32_t *)(b + o.free_); p.qcnt = (unsigned long long *)(b + o.cnt);
         p.q_retry = (uint32_t *)(b + o.retry); p.retry_shard_cap = (uint32_t)retry_shard_cap;
@@ -1237,8 +1225,8 @@ static int lane_enqueue(ptmi_ctx *ctx, Lane &L, Lane *other, const DevScene &sc,
     const size_t ray_lds = (size_t)(6 + 4 * pl.nshadow) * 256 * sizeof(float);
     if (ray_lds > (28u << 10))      // beyond the default 64 KB of LDS per workgroup (gfx950 has 160 KB)
         PTMI_HIP(ctx, hipFuncSetAttribute((const void *)shade_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds));
-    hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), ray_lds, L.st, pl, sc, ra, pl.q_ext_ray[cur], L.n_ext,
-                       pl.q_shpath[cur], L.n_shp, pl.q_ext_ray[cur ^ 1], pl.q_shpath[cur ^ 1],
+    hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), ray_lds, L.st, pl, sc, ra, pl.q_ext_ray[cur],
+                       pl.q_ext_arg[cur], L.n_ext, pl.q_shpath[cur], L.n_shp, pl.q_ext_ray[cur ^ 1], pl.q_ext_arg[cur ^ 1], pl.q_shpath[cur ^ 1],
                        qc(QC_EXT0 + (cur ^ 1)), qc(QC_SHP0 + (cur ^ 1)), ctx->d_counters);
     PTMI_HIP(ctx, hipGetLastError());
     PTMI_HIP(ctx, hipMemcpyAsync(L.hc, pl.qcnt, qc_bytes, hipMemcpyDeviceToHost, L.st));
@@ -1265,7 +1253,7 @@ static int lane_finish(ptmi_ctx *ctx, Lane &L, const RenderArgs &ra) {
     if (n_free && L.next_sample < L.end_sample) {
         const uint32_t ng = (uint32_t)std::min<uint64_t>(n_free, L.end_sample - L.next_sample);
         hipLaunchKernelGGL(generate_kernel, dim3((ng + 255) / 256), dim3(256), 0, L.st, pl, ra, (const uint32_t *)pl.q_free, ng,
-                           L.next_sample, pl.q_ext_ray[nxt], ne);
+                           L.next_sample, pl.q_ext_ray[nxt], pl.q_ext_arg[nxt], ne);
         PTMI_HIP(ctx, hipGetLastError());
         L.next_sample += ng;
         ne += ng;
@@ -1373,7 +1361,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             const uint32_t n0 = (uint32_t)std::min<uint64_t>(cap, L[l].end_sample - L[l].next_sample);
             if (n0) {
                 hipLaunchKernelGGL(generate_kernel, dim3((n0 + 255) / 256), dim3(256), 0, L[l].st, L[l].pl, ra,
-                                   (const uint32_t *)nullptr, n0, L[l].next_sample, L[l].pl.q_ext_ray[0], 0u);
+                                   (const uint32_t *)nullptr, n0, L[l].next_sample, L[l].pl.q_ext_ray[0], L[l].pl.q_ext_arg[0], 0u);
                 PTMI_HIP(ctx, hipGetLastError());
             }
             L[l].next_sample += n0;
