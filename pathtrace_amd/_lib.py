@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptmi.so")
+# PTMI_LIB: another build of the same library (A/B and ablation builds of tools/build_variant.sh); never a fallback
+LIB_PATH = os.environ.get("PTMI_LIB") or os.path.join(_HERE, "libptmi.so")
 
 PTMI_OK = 0
 ERR_NAMES = {-1: "PTMI_ERR_INVALID", -2: "PTMI_ERR_NO_DEVICE", -3: "PTMI_ERR_HIP", -4: "PTMI_ERR_NO_BVH",

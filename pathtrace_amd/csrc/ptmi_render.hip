@@ -24,22 +24,37 @@
 
 using namespace ptmi;
 
+// Timing-only ablation builds (tools/build_variant.sh <name> -DPTMI_ABLATE=<bits>): each bit removes one piece of shade's
+// memory traffic to price it; the images of such builds are wrong.  0 in the product.
+#ifndef PTMI_ABLATE
+#define PTMI_ABLATE 0
+#endif
+#define ABL(bit) ((PTMI_ABLATE) & (bit))
+
 namespace {
 
 constexpr int WAVE = 64;
+// workgroup barrier for data exchanged through LDS only: waits for this wave's LDS operations, not for its global
+// stores (hipcc's __syncthreads() also drains vmcnt, i.e. every frame / queue store the wave has in flight)
+__device__ __forceinline__ void lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---- frame fields (one frame per TraceRay invocation on the explicit recursion stack) ----------
 // A frame is 32 words = one 128-byte line, stored per path ([slot][depth][32]): shade loads the top
 // frame with eight 16-byte loads into registers, works on it there and writes it back when the path
 // parks (queue order is arbitrary, so a [field][slot] layout costs one 32/64-byte sector per word).
 enum {
-    F_BOUNCES = 0, F_BINDEX = 1, F_FLAGS = 2, F_ENERGY = 3, F_LN = 4,      // inputs of TraceRay (:15)
+    F_BB = 0,                                                              // bounces | bounceIndex << 16 | flags << 24 (inputs of TraceRay, :15)
+    F_SP = 1,                                                              // sample counter of the GI / reflection loop | phase << 24
+    F_MAT = 2, F_ENERGY = 3, F_LN = 4,
     F_RO = 7, F_RD = 10, F_T = 13, F_PRIM = 14,                            // the hit being shaded
-    F_DG = 15, F_DIFF = 16,                                                // doppler*gravity, diffuse component
-    F_REFR = 19, F_ALBEDO = 22, F_SUM = 25, F_S = 28, F_PHASE = 29, F_NEED = 30, F_MAT = 31,
+    F_DG = 15,                                                             // doppler * gravity
+    F_DIFF = 16,                                                           // diffuse component; until HandleDiffuseMaterial's final sum: its direct lighting
+    F_REFR = 19, F_ALBEDO = 22, F_SUM = 25,
+    F_PDIRECT = 28,                                                        // the CALLER's direct lighting, summed from the shadow terms this call carried
     // F_ALBEDO / F_MAT: what HandleDiffuseMaterial's final sum needs of the hit (textured albedo, material), kept in the
-    // frame so that a frame popped by a returning child does not gather its triangle record again
-    NF = 32, FRW = 32
+    // frame so that a frame popped by a returning child does not gather its triangle record again.
+    // A frame is one 128-byte line in memory (32 words, the last one unused) and FRW words of LDS while it is on top.
+    NF = 31, FRW = 31
 };
 enum { FL_SPECULAR = 1, FL_FLIPPED = 2 };
 // what the top frame is waiting for
@@ -108,13 +123,14 @@ struct Pool {
     int nframes, ntrk, nshadow;          // bounces+1, tracker history capacity (multiple of 4), nlights+2
     float4 *fr;                          // [cap][nframes][8]   frames (F_*)
     float *trk;                          // [cap][ntrk]         RefractiveIndexTracker.indices 1 .. (entry 0 travels with the path)
-    float4 *sh;                          // [cap][nframes][nshadow]  (contribution.xyz, occluded as u32 bits) per frame
     // queues
     float4 *q_ext_ray[2];                // extend queue (double buffered), 2 x float4 per entry: (o.xyz, bits(slot)) / (d.xyz, V_t0)
     float4 *q_ext_arg[2];                // ... its pending-call state, QA x float4 per entry
     float4 *q_ext_hit;                   // ... extend's answer, one float4 per entry of the queue being traced
     float4 *q_shpath[2];                 // paths waiting for their shadow rays, 2 x float4 per entry
-    float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, bits(index into sh))
+    float4 *q_ext_sh[2], *q_shp_sh[2];   // shadow terms that travel with an entry of either queue: nshadow x (term.xyz, bits(position of the ray))
+    float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, -)
+    uint32_t *q_sray_occ;                // connect's answers, by position in the shadow-ray queue (0 free, 1 occluded)
     uint32_t *q_retry; uint32_t retry_shard_cap;   // shadow rays a connect wave gave up on (RETRY_SHARDS regions), see connect
     uint32_t *q_free;                    // slots that finished in the last shade pass
     unsigned long long *qcnt;            // QC_COUNT counters, QC_STRIDE words apart
@@ -292,9 +308,7 @@ __global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool p
             TravCounters tc;
             res = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc) ? 1 : 0;
         }
-        const uint32_t target = f2u(bb.w);
-        if (target >= pl.cap * (uint32_t)pl.nframes * (uint32_t)pl.nshadow) atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
-        else if (res < 2) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = (uint32_t)res;
+        if (res < 2) pl.q_sray_occ[i] = (uint32_t)res;          // the answer goes beside the ray, by queue position
         // the wave's stragglers: one atomic on this wave's retry region, then the ray numbers
         const uint32_t shard = blockIdx.x % RETRY_SHARDS;
         const uint32_t pos = wave_append(pl.qcnt + (size_t)(QC_COUNT + shard) * QC_STRIDE, res == 2);
@@ -322,9 +336,7 @@ __global__ __launch_bounds__(WAVE) void render_connect_retry_kernel(DevBVH bvh, 
     const float4 a = pl.q_sray_a[i], bb = pl.q_sray_b[i];
     TravCounters tc;
     const bool occ = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc);
-    const uint32_t target = f2u(bb.w);
-    if (target < pl.cap * (uint32_t)pl.nframes * (uint32_t)pl.nshadow) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = occ ? 1u : 0u;
-    else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
+    pl.q_sray_occ[i] = occ ? 1u : 0u;
 }
 
 // connect: persistent waves walking vote-scheduled single steps (vote_walk, trav_device.hpp), shadow rays dealt in
@@ -337,22 +349,18 @@ __global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, P
     uint64_t n = 0;
 #pragma unroll
     for (int k = 0; k < NSB; ++k) n += sn.n[k];
-    const uint32_t ntargets = pl.cap * (uint32_t)pl.nframes * (uint32_t)pl.nshadow;
     TravCounters cnt;
     vote_walk<WAVE, true, false, uint32_t>(
         bvh, smem + threadIdx.x, n, cursor, refill_min, tri_bias, chunk_rays, cnt,
-        [&](uint64_t idx, NextRay &nx, uint32_t &target) {
+        [&](uint64_t idx, NextRay &nx, uint32_t &pos) {
             uint32_t rem = (uint32_t)idx, b = 0;             // bucket b, entry rem
 #pragma unroll
             for (int q = 0; q < NSB - 1; ++q) if (b == (uint32_t)q && rem >= sn.n[q]) { rem -= sn.n[q]; b = q + 1; }
             const size_t e = (size_t)b * pl.cap + rem;
             const float4 a = pl.q_sray_a[e], bb = pl.q_sray_b[e];
-            nx.ox = a.x; nx.oy = a.y; nx.oz = a.z; nx.tmax = a.w; nx.dx = bb.x; nx.dy = bb.y; nx.dz = bb.z; target = f2u(bb.w);
+            nx.ox = a.x; nx.oy = a.y; nx.oz = a.z; nx.tmax = a.w; nx.dx = bb.x; nx.dy = bb.y; nx.dz = bb.z; pos = (uint32_t)e;
         },
-        [&](uint32_t target, const RayTrav &r) {
-            if (target < ntargets) ((uint32_t *)pl.sh)[(size_t)target * 4 + 3] = r.best ? 1u : 0u;
-            else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
-        });
+        [&](uint32_t pos, const RayTrav &r) { pl.q_sray_occ[pos] = r.best ? 1u : 0u; });   // the answer goes beside the ray
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
 }
 
@@ -380,42 +388,61 @@ __device__ __forceinline__ bool is_emissive(const PtMaterial &m) { return m.ke[0
 // States of the per-path machine inside one shade invocation.
 enum { ST_EXTENDED, ST_MATERIAL, ST_SHADOW_DONE, ST_GI_LOOP, ST_REFL_LOOP, ST_DIFFUSE_FINAL, ST_COMBINE, ST_RETURN };
 
-// list_a = the extend queue just traced (entries 0 .. na-1: ray, pending-call state, extend's answer, all read
-// coalesced), list_b = the shadow-wait queue (nb parked frames whose shadow rays connect has answered).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, const float4 *list_a,
-                                                    const float4 *list_a_arg, uint32_t na, const float4 *list_b, uint32_t nb,
-                                                    float4 *q_ray_next, float4 *q_arg_next, float4 *q_shpath_next,
-                                                    unsigned long long *qc_ext_next, unsigned long long *qc_shp_next,
-                                                    unsigned long long *counters) {
+// LDS of one shade workgroup: the top frame of every thread (FRW words) and its staged shadow rays (SRW words each),
+// [word][thread].  160 KB per CU / 3 workgroups = 106 allocation granules of 512 bytes = 53 words per thread: a scene
+// with three shadow-ray kinds (sky sample, one light, emissive sample) takes 31 + 20 = 51 -- measured, 53 words already
+// leave only two workgroups resident (tools/lds_probe.hip: the occupancy API still says three) -- which is why the
+// workgroup's queue bookkeeping aliases the frame area (dead once a wave has left the state machine), the flags share
+// a frame word with the bounce counters, and neither the rays' origins (they follow from the hit point) nor the sky
+// sample's constant range are staged.
+// staged per shadow ray: direction, contribution, range -- the sky sample (kind 0) has a constant range (:538) and
+// takes 6 words, every other kind 7
+enum { SRW = 7 };
+__device__ __forceinline__ int stage_word(int k) { return k == 0 ? 0 : SRW * k - 1; }
+constexpr float SKY_RAY_RANGE = 100000.0f;
+
+// Reads the extend queue just traced (entries 0 .. na-1 of buffer `cur`: ray, pending-call state, extend's answer, the
+// parent's shadow terms, all coalesced) and the shadow-wait queue (nb parked frames whose shadow rays connect has
+// answered); writes the next buffers.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, int cur, uint32_t na,
+                                                                                               uint32_t nb, unsigned long long *counters) {
     __shared__ float s_fw[FRW * 256];
-    // a path's shadow rays wait here, [word][thread], until the workgroup has reserved their queue entries: the two
-    // origins they start from (words 0-2: sky and light rays, 3-5: the emissive-triangle ray), then direction and
-    // range of ray k in words 6+4k .. 9+4k: (6 + 4 * nshadow) * 256 floats of dynamic LDS
-    extern __shared__ float s_ray[];
-    __shared__ uint32_t s_q[3 + NSB][4];       // [queue][wave]: counts, then bases (ext, shadow paths, free, NSB ray buckets)
+    extern __shared__ float s_ray[];           // (SRW * nshadow - 1) * 256 floats
+    const float4 *list_a = pl.q_ext_ray[cur], *list_a_arg = pl.q_ext_arg[cur], *list_a_sh = pl.q_ext_sh[cur];
+    const float4 *list_b = pl.q_shpath[cur], *list_b_sh = pl.q_shp_sh[cur];
+    float4 *q_ray_next = pl.q_ext_ray[cur ^ 1], *q_arg_next = pl.q_ext_arg[cur ^ 1], *q_ext_sh_next = pl.q_ext_sh[cur ^ 1];
+    float4 *q_shpath_next = pl.q_shpath[cur ^ 1], *q_shp_sh_next = pl.q_shp_sh[cur ^ 1];
+    unsigned long long *qc_ext_next = pl.qcnt + (size_t)(QC_EXT0 + (cur ^ 1)) * QC_STRIDE;
+    unsigned long long *qc_shp_next = pl.qcnt + (size_t)(QC_SHP0 + (cur ^ 1)) * QC_STRIDE;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < na + nb;
     uint32_t slot = 0;
     bool want_extend = false, want_shadow = false, finished = false;
     uint32_t n_sray = 0;                       // shadow rays this path wants to enqueue
-    uint32_t need_out = 0;                     // their slots (bit k = shadow slot k)
-    int stage_depth = 0;                       // depth of the frame that cast them (its shadow slots take the answers)
+    uint32_t need_out = 0;                     // their kinds (bit k = shadow ray kind k)
     uint32_t diffuse_events = 0;
     V3 out_o = mk(0, 0, 0), out_d = mk(0, 0, 0);   // the ray of a path that wants an extend (goes into its queue entry)
     float4 out_a0 = make_float4(0, 0, 0, 0), out_a1 = out_a0, out_a2 = out_a0;   // ... and its pending-call state
+    V3 sh_o = mk(0, 0, 0), sh_eo = mk(0, 0, 0);    // origins of the staged shadow rays (sky / light rays; emissive sample)
     if (live) {
         const bool pending = i < na;                                        // the extend list holds exactly the pending calls
         float4 qa = make_float4(0, 0, 0, 0), qb = qa, a0, a1 = qa, a2, hq = qa;
+        uint32_t pneed = 0;                                                 // shadow terms that arrive with this entry
+        const float4 *pterms;
         if (pending) {
             qa = list_a[2 * (size_t)i]; qb = list_a[2 * (size_t)i + 1];
             a0 = list_a_arg[QA * (size_t)i]; a1 = list_a_arg[QA * (size_t)i + 1]; a2 = list_a_arg[QA * (size_t)i + 2];
             hq = pl.q_ext_hit[i];
             slot = f2u(qa.w);
+            pneed = f2u(a1.z) >> 8;
+            pterms = list_a_sh + (size_t)i * pl.nshadow;
         } else {
             const float4 e0 = list_b[2 * (size_t)(i - na)], e1 = list_b[2 * (size_t)(i - na) + 1];
             slot = f2u(e0.x);
             a0 = make_float4(e0.y, e0.z, e0.w, e1.x);
             a2 = make_float4(0.0f, 0.0f, 0.0f, e1.y);
+            pneed = f2u(e1.z);
+            pterms = list_b_sh + (size_t)(i - na) * pl.nshadow;
         }
         uint32_t err = 0;
         if (slot >= pl.cap) { err = ERR_SLOT; slot = 0; }
@@ -431,11 +458,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float ht = hq.z, vt0 = qb.w, vt1 = hq.w;
         V3 cur_o = mk(qa.x, qa.y, qa.z), cur_d = mk(qb.x, qb.y, qb.z);      // the path's current ray (pending calls only)
         float *trk = pl.trk + (size_t)slot * pl.ntrk;
+        // The direct lighting of the frame that cast the shadow rays whose terms arrived with this entry -- the caller
+        // of a pending call, or the parked frame itself: the contributions of the rays connect found free, added in
+        // the order of HandleDiffuseMaterial (sky sample :538-540, lights :557-559, emissive sample :617).
+        V3 pdirect = mk(0, 0, 0);
+        if (pneed >> pl.nshadow) { err |= ERR_PHASE; pneed = 0; }
+        for (int k = 0; k < pl.nshadow; ++k) {
+            if (!(pneed >> k & 1u)) continue;
+            const float4 v = pterms[k];
+            uint32_t qi = f2u(v.w);
+            if (qi >= pl.cap * (uint32_t)pl.nshadow) { err |= ERR_SLOT; qi = 0; }
+            if (pl.q_sray_occ[qi] == 0u) pdirect = add(pdirect, mk(v.x, v.y, v.z));
+        }
         // arguments of a child call pushed in this invocation (they go into its queue entry when the path parks)
         int arg_bounces = 0, arg_bindex = 0; uint32_t arg_flags = 0; float arg_energy = 0.0f; V3 arg_ln = mk(0, 0, 0);
         float4 *frames = pl.fr + (size_t)slot * pl.nframes * 8;
-        // shadow slots of the frame at depth `dep`
-        auto shp_at = [&](int dep) -> float4 * { return pl.sh + ((size_t)slot * pl.nframes + dep) * pl.nshadow; };
 
         // The top frame lives in LDS, [word][thread] (conflict-free): it is read and written all over the state
         // machine below, and 32 more loop-carried registers per lane are what this kernel cannot afford.
@@ -444,12 +481,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         auto load_frame = [&](int dep) {
             const float4 *f = frames + (size_t)dep * 8;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const float4 v = f[k]; FW(4 * k) = v.x; FW(4 * k + 1) = v.y; FW(4 * k + 2) = v.z; FW(4 * k + 3) = v.w; }
+            for (int k = 0; k < 8; ++k) { const float4 v = f[k]; FW(4 * k) = v.x; FW(4 * k + 1) = v.y; FW(4 * k + 2) = v.z; if (4 * k + 3 < FRW) FW(4 * k + 3) = v.w; }
         };
         auto store_frame = [&](int dep) {
             float4 *f = frames + (size_t)dep * 8;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] = make_float4(FW(4 * k), FW(4 * k + 1), FW(4 * k + 2), FW(4 * k + 3));
+            for (int k = 0; k < 8; ++k) f[k] = make_float4(FW(4 * k), FW(4 * k + 1), FW(4 * k + 2), 4 * k + 3 < FRW ? FW(4 * k + 3) : 0.0f);
         };
 #define FV(field) mk(FW(field), FW((field) + 1), FW((field) + 2))
 #define FV_SET(field, v) do { V3 v__ = (v); FW(field) = v__.x; FW((field) + 1) = v__.y; FW((field) + 2) = v__.z; } while (0)
@@ -457,6 +494,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #define FU(field) f2u(FW(field))
 #define FI_SET(field, v) (FW(field) = i2f(v))
 #define FU_SET(field, v) (FW(field) = u2f(v))
+        // bounces | bounceIndex << 16 | flags << 24 and sample counter | phase << 24 share a word each
+        auto f_bounces = [&]() -> int { return (int)(int16_t)(FU(F_BB) & 0xFFFFu); };
+        auto f_bindex = [&]() -> int { return (int)((FU(F_BB) >> 16) & 0xFFu); };
+        auto f_flags = [&]() -> uint32_t { return FU(F_BB) >> 24; };
+        auto set_flags = [&](uint32_t fl) { FU_SET(F_BB, (FU(F_BB) & 0xFFFFFFu) | fl << 24); };
+        auto f_s = [&]() -> int { return (int)(FU(F_SP) & 0xFFFFFFu); };
+        auto f_phase = [&]() -> uint32_t { return FU(F_SP) >> 24; };
+        auto set_s = [&](int s) { FU_SET(F_SP, (FU(F_SP) & 0xFF000000u) | ((uint32_t)s & 0xFFFFFFu)); };
+        auto set_phase = [&](uint32_t ph) { FU_SET(F_SP, (FU(F_SP) & 0xFFFFFFu) | ph << 24); };
         // RefractiveIndexTracker.indices: entry 0 in a register (it travels with the path), the rest in Pool::trk
         auto trk_get = [&](uint32_t e) -> float { return e == 0 ? trk0 : trk[e - 1]; };
         auto trk_set = [&](uint32_t e, float v) { if (e == 0) trk0 = v; else trk[e - 1] = v; };
@@ -474,7 +520,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (tr.mat >= sc.nmats) { err |= ERR_MAT; tr.mat = 0; }
             h.A = tr.A; h.B = tr.B; h.C = tr.C;
             V3 n = normalize(interpolate_normal(h.P, h.A, h.B, h.C, tr.N0, tr.N1, tr.N2));   // :38-46
-            if (FU(F_FLAGS) & FL_FLIPPED) n = scale(n, -1.0f);                      // :53
+            if (f_flags() & FL_FLIPPED) n = scale(n, -1.0f);                        // :53
             h.normal = n;
             h.mat = tr.mat;
             h.dnormal = n;
@@ -495,13 +541,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         bool have_hit = false;
         // entry: a pending call starts from its arguments, a parked frame comes back with its shadow answers
         if (pending) {
-            FW(F_BOUNCES) = a1.x; FW(F_BINDEX) = a1.y; FW(F_FLAGS) = a1.z; FW(F_ENERGY) = a1.w;
+            const int ab = f2i(a1.x), abi = f2i(a1.y);
+            FU_SET(F_BB, ((uint32_t)ab & 0xFFFFu) | ((uint32_t)abi & 0xFFu) << 16 | (f2u(a1.z) & 0xFFu) << 24);
+            FW(F_ENERGY) = a1.w;
             FW(F_LN) = a2.x; FW(F_LN + 1) = a2.y; FW(F_LN + 2) = a2.z;
-            FU_SET(F_PHASE, PH_EXTEND);
+            FV_SET(F_PDIRECT, pdirect);                                     // handed back to the caller when this call returns
+            FU_SET(F_SP, (uint32_t)PH_EXTEND << 24);
             state = ST_EXTENDED;
         } else {
             load_frame(depth);
-            if (FU(F_PHASE) == PH_SHADOW_WAIT) state = ST_SHADOW_DONE;
+            if (f_phase() == PH_SHADOW_WAIT) { FV_SET(F_DIFF, pdirect); state = ST_SHADOW_DONE; }
             else { err |= ERR_PHASE; state = ST_RETURN; depth = 0; }
         }
         for (;;) {
@@ -509,11 +558,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)err);
                 float *o = pl.out + 3 * (size_t)(sid < ra.total ? sid : 0);
                 o[0] = o[1] = o[2] = 0.0f;
-                want_extend = want_shadow = false; n_sray = 0; finished = true; break;
+                want_extend = want_shadow = false; n_sray = 0; need_out = 0; finished = true; break;
             }
             if (state == ST_EXTENDED) {
                 // TraceRay entry test (tracer.go:16) for the primary ray; children are tested before being pushed
-                if (FI(F_BOUNCES) < 0 || FW(F_ENERGY) < (float)1e-2) { ret = mk(0, 0, 0); state = ST_RETURN; continue; }
+                if (f_bounces() < 0 || FW(F_ENERGY) < (float)1e-2) { ret = mk(0, 0, 0); state = ST_RETURN; continue; }
                 if (hs == HS_HORIZON) { ret = mk(0, 0, 0); state = ST_RETURN; continue; }           // :253-255
                 if (hs == HS_MISS) {                                                                // :260-263
                     ret = sc.sky.kind == PTMI_SKY_NONE ? mk(0, 0, 0) : sky_sample(sc.sky, sc.sky_img, cur_d);
@@ -521,7 +570,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
                 FV_SET(F_RO, cur_o); FV_SET(F_RD, cur_d);
                 FW(F_T) = ht; FI_SET(F_PRIM, hprim);
-                FU_SET(F_FLAGS, FU(F_FLAGS) & ~(uint32_t)FL_FLIPPED);
+                set_flags(f_flags() & ~(uint32_t)FL_FLIPPED);
                 load_hit(h); have_hit = true;
                 FV_SET(F_ALBEDO, h.albedo); FU_SET(F_MAT, h.mat);
                 const PtMaterial &m = sc.mats[h.mat];
@@ -545,12 +594,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     bool goingOut = false;
                     if (dot(h.normal, h.rd) > 0.0f) {
                         h.normal = scale(h.normal, -1.0f); goingOut = true; ri = trk_previous();
-                        FU_SET(F_FLAGS, FU(F_FLAGS) | FL_FLIPPED);
+                        set_flags(f_flags() | FL_FLIPPED);
                     }
                     bool tir;
                     V3 rdir = get_refracted_ray(h.rd, h.normal, trk_current(), ri, tir);
                     V3 rorg = add(h.P, scale(rdir, (float)0.001));
-                    const int bounces = FI(F_BOUNCES), bindex = FI(F_BINDEX);
+                    const int bounces = f_bounces(), bindex = f_bindex();
                     const float energy = FW(F_ENERGY);
                     int cbi = bindex + 1;
                     if (!tir) {
@@ -559,8 +608,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     }
                     const float ce = energy * (float)0.95;
                     if (!(ce < (float)1e-2 || bounces - 1 < 0)) {
-                        FU_SET(F_PHASE, PH_REFR_WAIT);
-                        push_child(depth, bounces - 1, cbi, FV(F_LN), (FU(F_FLAGS) & FL_SPECULAR) != 0, ce, rorg, rdir);
+                        set_phase(PH_REFR_WAIT);
+                        push_child(depth, bounces - 1, cbi, FV(F_LN), (f_flags() & FL_SPECULAR) != 0, ce, rorg, rdir);
                         depth++; want_extend = true; break;
                     }
                     // the child returns Vec3{} at its entry test: refraction = {} * energy
@@ -577,12 +626,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if (reflectivity < (float)0.1) take_reflective = false;
                 else if (reflectivity < (float)0.9) take_reflective = rng_f32(rng) < reflectivity;  // :163
                 else take_reflective = true;
-                FV_SET(F_SUM, mk(0, 0, 0)); FI_SET(F_S, 0);
+                FV_SET(F_SUM, mk(0, 0, 0)); set_s(0);
                 if (take_reflective) { state = ST_REFL_LOOP; continue; }
-                const int bindex = FI(F_BINDEX);
+                const int bindex = f_bindex();
                 if (bindex > 0 && is_emissive(m)) {                                                 // :461-465
                     V3 dc = mk(m.ke);
-                    if (!(FU(F_FLAGS) & FL_SPECULAR)) {                                             // :143-158
+                    if (!(f_flags() & FL_SPECULAR)) {                                               // :143-158
                         float pdf_brdf = dot(h.rd, FV(F_LN)) / PT_PI32;
                         float area = triangle_area(h.A, h.B, h.C);
                         float pdf_area = 1.0f / ((float)sc.nemissive * area);
@@ -594,31 +643,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     FV_SET(F_DIFF, dc);
                     state = ST_COMBINE; continue;
                 }
-                // direct lighting of HandleDiffuseMaterial (:523-618): draw in the reference's order, stage the
-                // shadow rays, resume in ST_SHADOW_DONE once `connect` has answered them
+                // direct lighting of HandleDiffuseMaterial (:523-618): draw in the reference's order and stage the shadow
+                // rays.  A ray's contribution is staged as the term the final sum adds if the ray is free (lights:
+                // albedo * Sample(...), :557-559); the terms travel with the path's next queue entry and are summed at its
+                // next visit, once `connect` has answered the rays.
                 const V3 albedo = h.albedo;
                 const V3 rayOrigin = add(h.P, scale(h.dnormal, (float)0.001));                       // :528
                 uint32_t need = 0;
-                auto stage = [&](int k, V3 o, V3 d, float range, V3 contrib) {
+                auto stage = [&](int k, V3 d, float range, V3 term) {
                     need |= 1u << k;
-                    shp_at(depth)[k] = make_float4(contrib.x, contrib.y, contrib.z, u2f(0u));
-                    float *so = s_ray + (k == pl.nshadow - 1 ? 3 : 0) * 256 + tid;     // rewritten per ray: same value
-                    so[0] = o.x; so[256] = o.y; so[512] = o.z;
-                    float *sr = s_ray + (size_t)(6 + 4 * k) * 256 + tid;
-                    sr[0] = d.x; sr[256] = d.y; sr[512] = d.z; sr[768] = range;
+                    float *sr = s_ray + (size_t)stage_word(k) * 256 + tid;
+                    sr[0] = d.x; sr[256] = d.y; sr[512] = d.z;
+                    sr[768] = term.x; sr[1024] = term.y; sr[1280] = term.z;
+                    if (k) sr[1536] = range;
                     n_sray++;
                 };
+                sh_o = rayOrigin;
                 if (sc.sky.kind != PTMI_SKY_NONE) {                                                 // :531-542
                     V3 t1, t2; tangent_frame(h.dnormal, t1, t2);
                     V3 rn = cosine_sample2(rng, h.dnormal, t1, t2);
-                    stage(0, rayOrigin, rn, 100000.0f, cmul(sky_sample(sc.sky, sc.sky_img, rn), albedo));
+                    stage(0, rn, SKY_RAY_RANGE, cmul(sky_sample(sc.sky, sc.sky_img, rn), albedo));
                 }
                 for (uint32_t li = 0; li < sc.nlights; ++li) {                                      // :545-560
                     const PtLight &L = sc.lights[li];
                     if (L.kind == PTMI_LIGHT_SUN) {                                                 // lights.go:18-28
                         V3 ld = mk(L.vec);
                         float ndotr = dot(ld, h.dnormal);
-                        if (!(ndotr < 0.0f)) stage(1 + li, rayOrigin, ld, ra.p.step_size, scale(mk(L.color), ndotr * L.intensity));
+                        if (!(ndotr < 0.0f)) stage(1 + li, ld, ra.p.step_size, cmul(albedo, scale(mk(L.color), ndotr * L.intensity)));
                     } else {                                                                        // lights.go:38-54
                         V3 ld = normalize(sub(mk(L.vec), rayOrigin));
                         V3 toLight = sub(mk(L.vec), rayOrigin);
@@ -627,12 +678,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         float ndotl = dot(h.dnormal, toLight);
                         if (!(ndotl <= 0.0f)) {
                             float att = 1.0f / (distance * distance);
-                            stage(1 + li, rayOrigin, ld, distance, scale(mk(L.color), ndotl * L.intensity * att));
+                            stage(1 + li, ld, distance, cmul(albedo, scale(mk(L.color), ndotl * L.intensity * att)));
                         }
                     }
                 }
                 if (sc.nemissive > 0) {                                                             // :562-618
                     V3 eo = add(h.P, scale(h.dnormal, (float)0.01));
+                    sh_eo = eo;
                     uint32_t choice = rng_intn(rng, sc.nemissive);
                     uint32_t et = sc.emissive[choice];
                     if (et >= sc.ntris) { err |= ERR_PRIM; et = 0; }
@@ -658,28 +710,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                             V3 brdf = scale(albedo, (float)(1.0 / 3.14159265358979323846));
                             ec = scale(cmul(le, brdf), geometryTerm * weight / pdf);
                         }
-                        stage(1 + (int)sc.nlights, eo, toLight, distance - (float)0.01, ec);
+                        stage(1 + (int)sc.nlights, toLight, distance - (float)0.01, ec);
                     }
                 }
-                FU_SET(F_NEED, need);
-                need_out = need; stage_depth = depth;
+                need_out = need;
+                FV_SET(F_DIFF, mk(0, 0, 0));         // this frame's direct lighting until the terms have been summed
                 // A frame with a GI child to wait for anyway does not park for its shadow rays: they are traced while
-                // the child is, and their answers are read in ST_DIFFUSE_FINAL (same draws, same sums, one visit less).
-                if (need && FI(F_BOUNCES) <= 0) { FU_SET(F_PHASE, PH_SHADOW_WAIT); store_frame(depth); want_shadow = true; break; }
-                state = FI(F_BOUNCES) > 0 ? ST_GI_LOOP : ST_DIFFUSE_FINAL; continue;                // :622
+                // the child is, their terms travel with the child's entry, and the child hands the sum back when it
+                // returns (same draws, same sums, one visit less).
+                if (need && f_bounces() <= 0) { set_phase(PH_SHADOW_WAIT); store_frame(depth); want_shadow = true; break; }
+                state = f_bounces() > 0 ? ST_GI_LOOP : ST_DIFFUSE_FINAL; continue;                  // :622
             }
             if (state == ST_SHADOW_DONE) {
-                state = FI(F_BOUNCES) > 0 ? ST_GI_LOOP : ST_DIFFUSE_FINAL; continue;
+                state = f_bounces() > 0 ? ST_GI_LOOP : ST_DIFFUSE_FINAL; continue;
             }
             if (state == ST_GI_LOOP) {                                                              // :636-647
-                const int s = FI(F_S);
+                const int s = f_s();
                 if (s < ra.p.scatter_rays) {
                     if (!have_hit) { load_hit(h); have_hit = true; }
                     V3 t1, t2; tangent_frame(h.dnormal, t1, t2);
                     V3 dir = cosine_sample2(rng, h.dnormal, t1, t2);
                     // bounces > 0 and the energy is this frame's own (already >= 1e-2): the child always runs
-                    FU_SET(F_PHASE, PH_GI_WAIT);
-                    push_child(depth, FI(F_BOUNCES) - 1, FI(F_BINDEX) + 1, h.dnormal, false,
+                    set_phase(PH_GI_WAIT);
+                    push_child(depth, f_bounces() - 1, f_bindex() + 1, h.dnormal, false,
                                FW(F_ENERGY), add(h.P, scale(h.dnormal, (float)0.001)), dir);
                     depth++; want_extend = true; break;
                 }
@@ -690,28 +743,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 uint32_t fmat = FU(F_MAT);
                 if (fmat >= sc.nmats) { err |= ERR_MAT; fmat = 0; }
                 const PtMaterial &m = sc.mats[fmat];
-                V3 indirect = FI(F_BOUNCES) > 0 ? FV(F_SUM) : mk(0, 0, 0);
-                // direct lighting from the answers of this frame's shadow rays
+                V3 indirect = f_bounces() > 0 ? FV(F_SUM) : mk(0, 0, 0);
                 const V3 albedo = FV(F_ALBEDO);
-                const uint32_t need = FU(F_NEED);
-                const float4 *shp = shp_at(depth);
-                V3 direct = mk(0, 0, 0);
-                auto term = [&](int k) -> V3 {          // contribution of shadow slot k if it was cast and not occluded
-                    if (!(need >> k & 1u)) return mk(0, 0, 0);
-                    const float4 v = shp[k];
-                    return f2u(v.w) == 0u ? mk(v.x, v.y, v.z) : mk(0, 0, 0);
-                };
-                if (sc.sky.kind != PTMI_SKY_NONE && (need & 1u)) {                                  // :538-540
-                    const float4 v = shp[0];
-                    if (f2u(v.w) == 0u) direct = add(direct, mk(v.x, v.y, v.z));
-                }
-                for (uint32_t li = 0; li < sc.nlights; ++li)                                        // :557-559
-                    direct = add(direct, cmul(albedo, term(1 + (int)li)));
-                if (sc.nemissive > 0) direct = add(direct, term(1 + (int)sc.nlights));   // :617
-                V3 fin = direct;
+                V3 fin = FV(F_DIFF);                 // direct lighting: the free shadow rays' terms (summed at entry / by the child)
                 fin = add(fin, scale(albedo, ra.p.ambient));
                 fin = add(fin, scale(indirect, 1.0f));
-                if (FI(F_BINDEX) == 0 && is_emissive(m)) fin = add(fin, mk(m.ke));
+                if (f_bindex() == 0 && is_emissive(m)) fin = add(fin, mk(m.ke));
                 diffuse_events++;
                 FV_SET(F_DIFF, fin);
                 FV_SET(F_SUM, mk(0, 0, 0));          // reflective component stays zero on this branch
@@ -721,9 +758,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 uint32_t fmat = FU(F_MAT);
                 if (fmat >= sc.nmats) { err |= ERR_MAT; fmat = 0; }
                 const PtMaterial &m = sc.mats[fmat];
-                const int bounces = FI(F_BOUNCES);
+                const int bounces = f_bounces();
                 bool pushed = false;
-                while (FI(F_S) < ra.p.scatter_rays) {
+                while (f_s() < ra.p.scatter_rays) {
                     if (!have_hit) { load_hit(h); have_hit = true; }
                     float roughness = 1.0f / (1.0f + m.ns / 100.0f);
                     float dp = dot(h.rd, h.normal);
@@ -731,11 +768,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     V3 sd = sample_glossy(rng, reflDir, roughness);
                     if (bounces - 1 < 0) {          // the child returns Vec3{} at its entry test (:16)
                         FV_SET(F_SUM, add(FV(F_SUM), mk(0, 0, 0)));
-                        FI_SET(F_S, FI(F_S) + 1);
+                        set_s(f_s() + 1);
                         continue;
                     }
-                    FU_SET(F_PHASE, PH_REFL_WAIT);
-                    push_child(depth, bounces - 1, FI(F_BINDEX) + 1, h.normal, true, FW(F_ENERGY),
+                    set_phase(PH_REFL_WAIT);
+                    push_child(depth, bounces - 1, f_bindex() + 1, h.normal, true, FW(F_ENERGY),
                                add(h.P, scale(h.normal, (float)0.001)), sd);
                     depth++; want_extend = true; pushed = true; break;
                 }
@@ -753,38 +790,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 ret = scale(fin, FW(F_DG));
                 state = ST_RETURN; continue;
             }
-            // ST_RETURN: hand `ret` to the caller frame
+            // ST_RETURN: hand `ret` to the caller frame, and with it the caller's direct lighting this call carried
             if (depth == 0) {
                 float *o = pl.out + 3 * (size_t)sid;
                 o[0] = ret.x; o[1] = ret.y; o[2] = ret.z;
                 finished = true; break;
             }
+            const V3 pd = FV(F_PDIRECT);
             depth--; have_hit = false;
             load_frame(depth);
-            const uint32_t ph = FU(F_PHASE);
+            const uint32_t ph = f_phase();
             if (ph == PH_REFR_WAIT) {                                                               // :78, :89
                 FV_SET(F_REFR, scale(ret, FW(F_ENERGY)));
                 state = ST_MATERIAL;
             } else if (ph == PH_GI_WAIT) {                                                          // :640-645
+                const int s = f_s();
+                if (s == 0) FV_SET(F_DIFF, pd);      // the first scattered ray carried this frame's shadow terms
                 V3 c = cmul(ret, FV(F_ALBEDO));
                 FV_SET(F_SUM, add(FV(F_SUM), c));
-                FI_SET(F_S, FI(F_S) + 1);
+                set_s(s + 1);
                 state = ST_GI_LOOP;
             } else {                                                                                // PH_REFL_WAIT :715
                 FV_SET(F_SUM, add(FV(F_SUM), ret));
-                FI_SET(F_S, FI(F_S) + 1);
+                set_s(f_s() + 1);
                 state = ST_REFL_LOOP;
             }
         }
         if (err && !finished) {
             atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)err);
-            want_extend = want_shadow = false; n_sray = 0; finished = true;
+            want_extend = want_shadow = false; n_sray = 0; need_out = 0; finished = true;
         }
         if (!finished) {      // the state that travels with the path, for its next queue entry
             out_a0 = make_float4(a0.x, a0.y, u2f(rng.ctr), u2f((uint32_t)depth | trk_len << 8));
             out_a2 = make_float4(arg_ln.x, arg_ln.y, arg_ln.z, trk0);
+            // the child pushed right after staging carries the staged rays' terms (need_out), any other child none
             if (want_extend) {
-                out_a1 = make_float4(i2f(arg_bounces), i2f(arg_bindex), u2f(arg_flags), arg_energy);
+                out_a1 = make_float4(i2f(arg_bounces), i2f(arg_bindex), u2f(arg_flags | need_out << 8), arg_energy);
                 out_o = cur_o; out_d = cur_d;
             }
         }
@@ -814,40 +855,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int b = 0; b < NSB - 1; ++b) m_ray[b] = __ballot((need_out >> b) & 1u);
         for (int off = 32; off > 0; off >>= 1) diffuse_events += __shfl_xor(diffuse_events, off);
+        // [queue][wave] counts, then bases (ext, shadow paths, free, NSB ray buckets), in the frame area: wave w uses
+        // words of its OWN threads' columns (frame word 0 of threads 64 w + q), which are dead now that the whole wave
+        // has left the state machine; other waves may still be in theirs
+        uint32_t *s_q = (uint32_t *)s_fw;
+#define SQ(q, w) s_q[(w) * 64 + (q)]
         if (lane == 63) {
-            s_q[0][wv] = (uint32_t)__popcll(m_ext); s_q[1][wv] = (uint32_t)__popcll(m_shp);
-            s_q[2][wv] = (uint32_t)__popcll(m_fin);
+            SQ(0, wv) = (uint32_t)__popcll(m_ext); SQ(1, wv) = (uint32_t)__popcll(m_shp);
+            SQ(2, wv) = (uint32_t)__popcll(m_fin);
 #pragma unroll
-            for (int b = 0; b < NSB - 1; ++b) s_q[3 + b][wv] = (uint32_t)__popcll(m_ray[b]);
-            s_q[3 + NSB - 1][wv] = pl.nshadow >= NSB ? incl : 0u;
+            for (int b = 0; b < NSB - 1; ++b) SQ(3 + b, wv) = (uint32_t)__popcll(m_ray[b]);
+            SQ(3 + NSB - 1, wv) = pl.nshadow >= NSB ? incl : 0u;
         }
-        __syncthreads();
+        lds_barrier();
         if (threadIdx.x < 3 + NSB) {
             const int q = threadIdx.x;
-            const uint32_t c0 = s_q[q][0], c1 = s_q[q][1], c2 = s_q[q][2], c3 = s_q[q][3];
+            const uint32_t c0 = SQ(q, 0), c1 = SQ(q, 1), c2 = SQ(q, 2), c3 = SQ(q, 3);
             const uint32_t total = c0 + c1 + c2 + c3;
             unsigned long long *ctr = q == 0 ? qc_ext_next : q == 1 ? qc_shp_next : &pl.qcnt[(size_t)(QC_FREE + (q - 2)) * QC_STRIDE];
             uint32_t base = 0;
             if (total) base = (uint32_t)atomicAdd(ctr, (unsigned long long)total);
-            s_q[q][0] = base; s_q[q][1] = base + c0; s_q[q][2] = base + c0 + c1; s_q[q][3] = base + c0 + c1 + c2;
+            SQ(q, 0) = base; SQ(q, 1) = base + c0; SQ(q, 2) = base + c0 + c1; SQ(q, 3) = base + c0 + c1 + c2;
             if (q == 2 && total) atomicAdd(&counter_shard(counters)[CNT_SAMPLES], (unsigned long long)total);
         }
         if (lane == 0 && diffuse_events) atomicAdd(&counter_shard(counters)[CNT_DIFFUSE], (unsigned long long)diffuse_events);
-        __syncthreads();
+        lds_barrier();
+        // where this path's shadow terms go: beside its extend entry or its shadow-wait entry
+        float4 *terms_out = nullptr;
         if (want_extend) {
-            const size_t pe = s_q[0][wv] + (uint32_t)__popcll(m_ext & lt);
+            const size_t pe = SQ(0, wv) + (uint32_t)__popcll(m_ext & lt);
             q_ray_next[2 * pe] = make_float4(out_o.x, out_o.y, out_o.z, u2f(slot));
             q_ray_next[2 * pe + 1] = make_float4(out_d.x, out_d.y, out_d.z, 1.0f);
             q_arg_next[QA * pe] = out_a0; q_arg_next[QA * pe + 1] = out_a1; q_arg_next[QA * pe + 2] = out_a2;
+            terms_out = q_ext_sh_next + pe * (size_t)pl.nshadow;
         }
         if (want_shadow) {
-            const size_t ps = s_q[1][wv] + (uint32_t)__popcll(m_shp & lt);
+            const size_t ps = SQ(1, wv) + (uint32_t)__popcll(m_shp & lt);
             q_shpath_next[2 * ps] = make_float4(u2f(slot), out_a0.x, out_a0.y, out_a0.z);
-            q_shpath_next[2 * ps + 1] = make_float4(out_a0.w, out_a2.w, 0.0f, 0.0f);
+            q_shpath_next[2 * ps + 1] = make_float4(out_a0.w, out_a2.w, u2f(need_out), 0.0f);
+            terms_out = q_shp_sh_next + ps * (size_t)pl.nshadow;
         }
-        if (finished) pl.q_free[s_q[2][wv] + (uint32_t)__popcll(m_fin & lt)] = slot;
-        if (n_sray) {
-            uint32_t pos_last = s_q[3 + NSB - 1][wv] + (incl - (uint32_t)__popc(last_bits));
+        if (finished) pl.q_free[SQ(2, wv) + (uint32_t)__popcll(m_fin & lt)] = slot;
+        if (n_sray && terms_out) {
+            uint32_t pos_last = SQ(3 + NSB - 1, wv) + (incl - (uint32_t)__popc(last_bits));
             for (int k = 0; k < pl.nshadow; ++k) {
                 if (!(need_out >> k & 1u)) continue;
                 uint32_t pos;
@@ -855,19 +905,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     unsigned long long m = 0;
 #pragma unroll
                     for (int b = 0; b < NSB - 1; ++b) if (b == k) m = m_ray[b];
-                    pos = s_q[3 + k][wv] + (uint32_t)__popcll(m & lt);
+                    pos = SQ(3 + k, wv) + (uint32_t)__popcll(m & lt);
                 } else {
                     pos = pos_last++;
                 }
                 const int b = k < NSB - 1 ? k : NSB - 1;
                 const size_t qi = (size_t)b * pl.cap + pos;
-                const float *so = s_ray + (k == pl.nshadow - 1 ? 3 : 0) * 256 + threadIdx.x;
-                const float *sr = s_ray + (size_t)(6 + 4 * k) * 256 + threadIdx.x;
-                const float4 a = make_float4(so[0], so[256], so[512], sr[768]);
-                const float4 bb = make_float4(sr[0], sr[256], sr[512], u2f((slot * (uint32_t)pl.nframes + (uint32_t)stage_depth) * (uint32_t)pl.nshadow + (uint32_t)k));
-                pl.q_sray_a[qi] = a; pl.q_sray_b[qi] = bb;
+                const V3 o = k == pl.nshadow - 1 ? sh_eo : sh_o;            // the emissive sample starts from its own offset (:563)
+                const float *sr = s_ray + (size_t)stage_word(k) * 256 + threadIdx.x;
+                pl.q_sray_a[qi] = make_float4(o.x, o.y, o.z, k ? sr[1536] : SKY_RAY_RANGE);
+                pl.q_sray_b[qi] = make_float4(sr[0], sr[256], sr[512], 0.0f);
+                terms_out[k] = make_float4(sr[768], sr[1024], sr[1280], u2f((uint32_t)qi));
             }
         }
+#undef SQ
     }
 }
 
@@ -961,7 +1012,7 @@ extern "C" int ptmi_upload_scene(ptmi_ctx *ctx, const PtMaterial *materials, uin
     const uint64_t ntris = ctx->tri_idx.size() / 3;
     if (!materials || !nmaterials || (!tri_material && ntris) || (!corner_normals && ntris) || !sky || (!lights && nlights))
         return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: null array");
-    // shade stages a path's shadow rays (one per light + 2) in LDS: 4 KB per ray kind beside the 32 KB of frames
+    // shade stages a path's shadow rays (one per light + 2) in LDS: 7 KB per ray kind beside the 32 KB of frames
     if (nlights > 16) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: at most 16 lights");
     for (uint64_t t = 0; t < ntris; ++t)
         if (tri_material[t] >= nmaterials) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: material index out of range");
@@ -1059,7 +1110,7 @@ static uint64_t pool_bytes_per_path(int bounces, int nlights) {
     const uint64_t nframes = (uint64_t)bounces + 1, nshadow = (uint64_t)nlights + 2;
     // frames + tracker history + shadow slots and shadow-ray queue + extend queue (ray, state: double buffered; answer) +
     // shadow-wait queue (double buffered) + free list + retry share
-    return 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (16 * nframes + 32) * nshadow + (32 + 16 * QA) * 2 + 16 + 32 * 2 + 4 + nshadow;
+    return 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (32 + 4 + 16 * 4) * nshadow + (32 + 16 * QA) * 2 + 16 + 32 * 2 + 4 + nshadow;
 }
 
 static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
@@ -1071,16 +1122,17 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     const int nframes = bounces + 1, nshadow = (int)rs->nlights + 2;
     const int ntrk = tracker_words(bounces);
     const size_t c = cap;
-    struct Off { size_t fr, trk, sh, qs0, qs1, ra, rb, qr0, qr1, qa0, qa1, qh, free_, cnt, retry; } of[2];
+    struct Off { size_t fr, trk, qs0, qs1, ra, rb, occ, qr0, qr1, qa0, qa1, qh, xs0, xs1, ss0, ss1, free_, cnt, retry; } of[2];
     // connect launches at most cap * nshadow / 64 + NSB waves
     const size_t retry_shard_cap = (((size_t)cap * nshadow / WAVE + NSB) / RETRY_SHARDS + 1) * BAIL_MAX;
     size_t off = 0;
     for (int l = 0; l < lanes; ++l) {
         Off &o = of[l];
         o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
-        o.sh = carve(off, 16 * c * nshadow * (size_t)nframes);
         o.qs0 = carve(off, 32 * c); o.qs1 = carve(off, 32 * c);
-        o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow);
+        o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow); o.occ = carve(off, 4 * c * nshadow);
+        o.xs0 = carve(off, 16 * c * nshadow); o.xs1 = carve(off, 16 * c * nshadow);
+        o.ss0 = carve(off, 16 * c * nshadow); o.ss1 = carve(off, 16 * c * nshadow);
         o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
         o.qa0 = carve(off, 16 * QA * c); o.qa1 = carve(off, 16 * QA * c); o.qh = carve(off, 16 * c);
         o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * (QC_COUNT + RETRY_SHARDS + 2) * QC_STRIDE);
@@ -1098,7 +1150,9 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
         Pool p{};
         p.cap = cap; p.nframes = nframes; p.nshadow = nshadow; p.ntrk = ntrk;
         p.fr = (float4 *)(b + o.fr); p.trk = (float *)(b + o.trk);
-        p.sh = (float4 *)(b + o.sh);
+        p.q_ext_sh[0] = (float4 *)(b + o.xs0); p.q_ext_sh[1] = (float4 *)(b + o.xs1);
+        p.q_shp_sh[0] = (float4 *)(b + o.ss0); p.q_shp_sh[1] = (float4 *)(b + o.ss1);
+        p.q_sray_occ = (uint32_t *)(b + o.occ);
         p.q_ext_ray[0] = (float4 *)(b + o.qr0); p.q_ext_ray[1] = (float4 *)(b + o.qr1);
         p.q_ext_arg[0] = (float4 *)(b + o.qa0); p.q_ext_arg[1] = (float4 *)(b + o.qa1);
         p.q_ext_hit = (float4 *)(b + o.qh);
@@ -1212,7 +1266,6 @@ struct Lane {
 static int lane_enqueue(ptmi_ctx *ctx, Lane &L, Lane *other, const DevScene &sc, const RenderArgs &ra) {
     Pool &pl = L.pl;
     const size_t qc_bytes = (size_t)QC_COUNT * QC_STRIDE * sizeof(unsigned long long);
-    auto qc = [&](int which) { return pl.qcnt + (size_t)which * QC_STRIDE; };
     const int cur = L.cur;
     PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, qc_bytes + (size_t)(RETRY_SHARDS + 2) * QC_STRIDE * sizeof(unsigned long long), L.st));
     if (other && other->ev_recorded) PTMI_HIP(ctx, hipStreamWaitEvent(L.st, other->ev_trav, 0));
@@ -1222,12 +1275,10 @@ static int lane_enqueue(ptmi_ctx *ctx, Lane &L, Lane *other, const DevScene &sc,
     if (nsr) launch_render_connect(ctx, pl, L.n_srays, L.st);
     if (other) { PTMI_HIP(ctx, hipEventRecord(L.ev_trav, L.st)); L.ev_recorded = true; }
     const uint32_t nshade = L.n_ext + L.n_shp;
-    const size_t ray_lds = (size_t)(6 + 4 * pl.nshadow) * 256 * sizeof(float);
+    const size_t ray_lds = (size_t)(SRW * pl.nshadow - 1) * 256 * sizeof(float);
     if (ray_lds > (28u << 10))      // beyond the default 64 KB of LDS per workgroup (gfx950 has 160 KB)
         PTMI_HIP(ctx, hipFuncSetAttribute((const void *)shade_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds));
-    hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), ray_lds, L.st, pl, sc, ra, pl.q_ext_ray[cur],
-                       pl.q_ext_arg[cur], L.n_ext, pl.q_shpath[cur], L.n_shp, pl.q_ext_ray[cur ^ 1], pl.q_ext_arg[cur ^ 1], pl.q_shpath[cur ^ 1],
-                       qc(QC_EXT0 + (cur ^ 1)), qc(QC_SHP0 + (cur ^ 1)), ctx->d_counters);
+    hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), ray_lds, L.st, pl, sc, ra, cur, L.n_ext, L.n_shp, ctx->d_counters);
     PTMI_HIP(ctx, hipGetLastError());
     PTMI_HIP(ctx, hipMemcpyAsync(L.hc, pl.qcnt, qc_bytes, hipMemcpyDeviceToHost, L.st));
     L.inflight = true;
