@@ -71,8 +71,7 @@ struct ptmi_ctx {
     int render_vote_chunk = 256;        // queue entries reserved per cursor atomic in the integrator's vote-scheduled kernels
     int segment_shortcut = 1;           // the curved march skips the walk for segments far outside the tree's tight box
     int connect_vote = 1;               // connect as a vote-scheduled persistent kernel (0: one-shot waves + hand-over)
-    int connect_bail_lanes = 16;        // connect: a wave hands its last N walking lanes to a second launch (0 = off)
-    int render_lanes = 1;               // path pools worked side by side (2 = pipelined lanes: measured 7 % slower, shade fills the VGPR file)
+    int render_batch_iters = 2;         // wavefront iterations enqueued between two looks at the queue counters (render_core)
     int vote_refill_min = 16;           // refill once this many lanes are idle
     int vote_tri_bias = -8;             // inner step wins the vote when nI + bias >= nT
     int vote_chunk = 128;               // rays reserved per cursor atomic (multiple of 64)

@@ -66,14 +66,24 @@ enum { HS_MISS = 0, HS_HIT = 1, HS_HORIZON = 2 };
 // beyond NSB-1 share the last bucket): a wave of the connect kernel then holds rays of one kind, which have similar
 // directions and lengths, instead of a mix in which the short ones idle until the longest has finished.
 enum { NSB = 8 };
-enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHP0 = 2, QC_SHP1 = 3, QC_FREE = 4, QC_SRAY = 5, QC_COUNT = QC_SRAY + NSB, QC_STRIDE = 16 };
+enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHP0 = 2, QC_SHP1 = 3, QC_FREE = 4, QC_SRAY = 5, QC_NEXT = QC_SRAY + NSB,   // QC_NEXT: next sample id to generate
+       QC_CURSOR = QC_NEXT + 1, QC_CURSOR_EXT = QC_CURSOR + 1,                  // ray cursors of the vote-scheduled kernels
+       QC_COUNT = QC_CURSOR_EXT + 1, QC_STRIDE = 16 };
 struct ShadowCounts { uint32_t n[NSB]; };
-// connect's retry queue: a wave whose last few lanes are still walking hands their rays to a second launch.  The queue
-// is split into RETRY_SHARDS regions, each with a counter on a line of its own (same-line atomics serialise); wave w
-// appends to region w % RETRY_SHARDS, at most BAIL_MAX rays, so a region of ceil(waves / RETRY_SHARDS) * BAIL_MAX
-// entries cannot overflow.  The counters follow the queue counters (one memset clears both).
-enum { RETRY_SHARDS = 256, BAIL_MAX = 16 };
-enum { QC_CURSOR = QC_COUNT + RETRY_SHARDS, QC_CURSOR_EXT = QC_CURSOR + 1 };     // ray cursors of the vote-scheduled kernels
+// The wavefront loop is driven from the device: at the start of an iteration a one-thread kernel (iter_prep_kernel)
+// turns the queue counters the last shade pass left behind into this iteration's arguments -- one 128-byte line that
+// every kernel of the iteration reads its work size from -- and clears the counters for the next pass.  The host
+// enqueues iterations without knowing their sizes (every kernel runs on a fixed grid and loops over its share) and only
+// looks at the counters once per batch of iterations, one batch behind the queue, to see whether the pool has drained.
+struct IterArgs {
+    uint32_t n_ext;                // entries of the extend queue to trace and shade (this iteration's fresh samples included)
+    uint32_t gen_n, gen_base;      // fresh samples to generate: entries gen_base .. gen_base + gen_n - 1, slots from the free list
+    uint32_t n_shp;                // parked frames whose shadow rays are answered in this iteration
+    ShadowCounts sray;             // shadow rays per bucket
+    uint32_t pad[3];
+    unsigned long long first_sample;
+};
+static_assert(sizeof(IterArgs) <= 128, "IterArgs is one line");
 // Path state that travels with the queues (no per-path header in memory):
 //   extend queue entry i = the pending TraceRay call of a path, three coalesced arrays per queue buffer:
 //     q_ext_ray[2i], [2i+1]  (o.xyz, bits(slot)) / (d.xyz, V_t at the start of the geodesic -- curved rays only)
@@ -91,7 +101,7 @@ enum { QC_CURSOR = QC_COUNT + RETRY_SHARDS, QC_CURSOR_EXT = QC_CURSOR + 1 };    
 enum { QA = 3 };
 
 // self-check failures reported through counters[CNT_ERROR] (a corrupted path is dropped, never dereferenced)
-enum { ERR_SLOT = 1, ERR_DEPTH = 2, ERR_PRIM = 4, ERR_MAT = 8, ERR_PHASE = 16 };
+enum { ERR_SLOT = 1, ERR_DEPTH = 2, ERR_PRIM = 4, ERR_MAT = 8, ERR_PHASE = 16, ERR_QUEUE = 32 };
 
 struct DevScene {
     const float4 *stri;                  // shading record per triangle, 5 x float4: A B C, N0 N1 N2, material id
@@ -131,9 +141,9 @@ struct Pool {
     float4 *q_ext_sh[2], *q_shp_sh[2];   // shadow terms that travel with an entry of either queue: nshadow x (term.xyz, bits(position of the ray))
     float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, -)
     uint32_t *q_sray_occ;                // connect's answers, by position in the shadow-ray queue (0 free, 1 occluded)
-    uint32_t *q_retry; uint32_t retry_shard_cap;   // shadow rays a connect wave gave up on (RETRY_SHARDS regions), see connect
     uint32_t *q_free;                    // slots that finished in the last shade pass
     unsigned long long *qcnt;            // QC_COUNT counters, QC_STRIDE words apart
+    IterArgs *it;                        // this iteration's arguments (iter_prep_kernel)
     float *out;                          // per-sample radiance [total][3]
 };
 
@@ -177,33 +187,75 @@ __device__ __forceinline__ void region_pixel(const RenderArgs &ra, uint32_t pix,
 // ------------------------------------------------------------------------------------------ generate
 // main.go:861-874 + the TraceRay call of :875 (bounceIndex 0, lastSurfaceNormal {}, not specular,
 // NewRefractiveIndexTracker(1.0), energy 1.0)
-// Every generated path goes to the extend queue, so its queue position needs no atomic: entry q_base + i.
-// A fresh sample is a pending call and nothing else: one ray entry and one argument entry, both written coalesced.
-__global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, const uint32_t *slots, uint32_t n,
-                                                       uint64_t first_sample, float4 *q_ray_next, float4 *q_arg_next, uint32_t q_base) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t slot = slots ? slots[i] : i;
-    const uint32_t sid = (uint32_t)first_sample + i;                       // total < 2^32/3 (render_core)
-    const uint32_t pix = sid / ra.spp_chunk, smp = sid % ra.spp_chunk;
-    int X, Y;
-    region_pixel(ra, pix, X, Y);
-    Rng rng = rng_init(ra.p.seed, (uint32_t)(Y * ra.p.width + X), ra.spp_begin + smp);
-    const float rx = ((float)X + rng_f32(rng)) / (float)ra.p.width;
-    const float ry = ((float)Y + rng_f32(rng)) / (float)ra.p.height;
-    const float px = (rx - 0.5f) * 2.0f, py = (ry - 0.5f) * 2.0f;
-    const V3 pos = mk(ra.cam.position), fwd = mk(ra.cam.forward), right = mk(ra.cam.right), up = mk(ra.cam.up);
-    const V3 rayOrigin = add(add(add(pos, scale(fwd, ra.cam.frustum_distance)), scale(up, py)), scale(right, px));
-    const V3 d = normalize(mk(rayOrigin.x - pos.x, rayOrigin.y - pos.y, rayOrigin.z - pos.z));
-    const size_t e = (size_t)q_base + i;
-    float4 *qr = q_ray_next + 2 * e;
-    qr[0] = make_float4(pos.x, pos.y, pos.z, u2f(slot));
-    qr[1] = make_float4(d.x, d.y, d.z, 1.0f);
-    // TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0; shade handles that case
-    float4 *qa = q_arg_next + QA * e;
-    qa[0] = make_float4(u2f(sid), u2f(rng.key), u2f(rng.ctr), u2f(0u | (1u << 8)));           // depth 0, tracker {1.0}
-    qa[1] = make_float4(i2f(ra.p.bounces), i2f(0), u2f(0u), 1.0f);                            // main.go:875
-    qa[2] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);                                              // lastSurfaceNormal {}, NewRefractiveIndexTracker(1.0)
+// Start of a call: every slot is free, nothing is queued.
+__global__ __launch_bounds__(256) void iter_init_kernel(Pool pl, uint32_t n0) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += stride) pl.q_free[i] = i;
+    if (blockIdx.x == 0 && threadIdx.x < QC_COUNT) pl.qcnt[(size_t)threadIdx.x * QC_STRIDE] = threadIdx.x == QC_FREE ? n0 : 0ull;
+}
+
+// Start of an iteration on queue buffer `cur` (see IterArgs).  One thread: a dozen counters.
+__global__ void iter_prep_kernel(Pool pl, int cur, unsigned long long total, unsigned long long *counters) {
+    if (blockIdx.x || threadIdx.x) return;
+    auto qc = [&](int w) -> unsigned long long & { return pl.qcnt[(size_t)w * QC_STRIDE]; };
+    const int nxt = cur ^ 1;
+    unsigned long long n_ext = qc(QC_EXT0 + cur), n_shp = qc(QC_SHP0 + cur), n_free = qc(QC_FREE), next = qc(QC_NEXT);
+    IterArgs a;
+    bool bad = n_ext > pl.cap || n_shp > pl.cap || n_free > pl.cap || next > total;
+    for (int b = 0; b < NSB; ++b) {
+        const unsigned long long n = qc(QC_SRAY + b);
+        const unsigned long long room = b < NSB - 1 ? (unsigned long long)pl.cap : (unsigned long long)pl.cap * (unsigned long long)max(pl.nshadow - (NSB - 1), 0);
+        bad = bad || n > room;
+        a.sray.n[b] = (uint32_t)n;
+    }
+    if (bad) {          // a counter out of range: raise the error word and let the pool run dry
+        atomicOr(&counters[CNT_ERROR], (unsigned long long)ERR_QUEUE);
+        n_ext = n_shp = n_free = 0; next = total;
+        for (int b = 0; b < NSB; ++b) a.sray.n[b] = 0;
+    }
+    unsigned long long ng = min(n_free, total - next);
+    if (n_ext + ng > pl.cap) ng = pl.cap - n_ext;
+    a.gen_n = (uint32_t)ng; a.gen_base = (uint32_t)n_ext; a.first_sample = next;
+    a.n_ext = (uint32_t)(n_ext + ng); a.n_shp = (uint32_t)n_shp;
+    a.pad[0] = a.pad[1] = a.pad[2] = 0;
+    *pl.it = a;
+    qc(QC_NEXT) = next + ng;
+    qc(QC_EXT0 + cur) = n_ext + ng;
+    qc(QC_EXT0 + nxt) = 0; qc(QC_SHP0 + nxt) = 0; qc(QC_FREE) = 0;
+    for (int b = 0; b < NSB; ++b) qc(QC_SRAY + b) = 0;
+    qc(QC_CURSOR) = 0; qc(QC_CURSOR_EXT) = 0;
+}
+
+// A fresh sample is a pending call and nothing else: one ray entry and one argument entry at the end of the extend
+// queue (no atomic: entry gen_base + i), both written coalesced; its slot comes from the free list.
+__global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, int cur) {
+    const uint32_t n = pl.it->gen_n, q_base = pl.it->gen_base;
+    const unsigned long long first_sample = pl.it->first_sample;
+    float4 *q_ray = pl.q_ext_ray[cur], *q_arg = pl.q_ext_arg[cur];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t slot = pl.q_free[i];
+        const uint32_t sid = (uint32_t)first_sample + i;                       // total < 2^32/3 (render_core)
+        const uint32_t pix = sid / ra.spp_chunk, smp = sid % ra.spp_chunk;
+        int X, Y;
+        region_pixel(ra, pix, X, Y);
+        Rng rng = rng_init(ra.p.seed, (uint32_t)(Y * ra.p.width + X), ra.spp_begin + smp);
+        const float rx = ((float)X + rng_f32(rng)) / (float)ra.p.width;
+        const float ry = ((float)Y + rng_f32(rng)) / (float)ra.p.height;
+        const float px = (rx - 0.5f) * 2.0f, py = (ry - 0.5f) * 2.0f;
+        const V3 pos = mk(ra.cam.position), fwd = mk(ra.cam.forward), right = mk(ra.cam.right), up = mk(ra.cam.up);
+        const V3 rayOrigin = add(add(add(pos, scale(fwd, ra.cam.frustum_distance)), scale(up, py)), scale(right, px));
+        const V3 d = normalize(mk(rayOrigin.x - pos.x, rayOrigin.y - pos.y, rayOrigin.z - pos.z));
+        const size_t e = (size_t)q_base + i;
+        float4 *qr = q_ray + 2 * e;
+        qr[0] = make_float4(pos.x, pos.y, pos.z, u2f(slot));
+        qr[1] = make_float4(d.x, d.y, d.z, 1.0f);
+        // TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0; shade handles that case
+        float4 *qa = q_arg + QA * e;
+        qa[0] = make_float4(u2f(sid), u2f(rng.key), u2f(rng.ctr), u2f(0u | (1u << 8)));           // depth 0, tracker {1.0}
+        qa[1] = make_float4(i2f(ra.p.bounces), i2f(0), u2f(0u), 1.0f);                            // main.go:875
+        qa[2] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);                                              // lastSurfaceNormal {}, NewRefractiveIndexTracker(1.0)
+    }
 }
 
 // ------------------------------------------------------------------------------------------ extend
@@ -211,14 +263,19 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, c
 // on a miss advance (straight) or RK4-step the geodesic (curved) and test the horizon.
 // Queue entries carry the ray and the answer goes into the queue's hit array, so the kernel touches no per-path memory;
 // it writes the ray back into its entry only when shade needs the moved one (a hit after marching, a curved ray).
+// Runs on a fixed grid and loops over the queue; leaves at once when the launch is large enough for the vote-scheduled
+// kernel to take it (vote_from).
 template <int STACK, bool CURVED>
-__global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl, DevScene sc, RenderArgs ra,
-                                                             float4 *__restrict__ qray, uint32_t n,
-                                                             unsigned long long *counters) {
+__global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl, DevScene sc, RenderArgs ra, int cur,
+                                                             uint32_t vote_from, unsigned long long *counters) {
     __shared__ uint32_t smem[STACK * WAVE];
-    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    const uint32_t n = pl.it->n_ext;
+    if (n >= vote_from) return;
+    float4 *__restrict__ qray = pl.q_ext_ray[cur];
     uint32_t nq = 0;
-    if (i < n) {
+    for (uint32_t base = blockIdx.x * WAVE; base < n; base += gridDim.x * WAVE) {
+        const uint32_t i = base + threadIdx.x;
+        if (i >= n) continue;
         const float4 qa = qray[2 * (size_t)i], qb = qray[2 * (size_t)i + 1];
         V3 o = mk(qa.x, qa.y, qa.z);
         V3 d = mk(qb.x, qb.y, qb.z);
@@ -262,16 +319,24 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
 // vote-scheduled single steps (vote_walk, trav_device.hpp), queue entries dealt in chunks from one cursor.  Same output
 // as render_extend_kernel: the answer into the queue's hit array (a ray that is traced once never moves before a hit,
 // and shade does not look at the origin of a miss, so the entry itself is never written back).
+// A persistent wave reserves three chunks of queue entries before it starts (one in use, two ahead): the chunk is
+// `chunk_max` entries when the launch feeds every wave that much, less for smaller launches (never below one wave's 64).
+__device__ __forceinline__ uint32_t vote_chunk(uint64_t n, uint32_t chunk_max) {
+    const uint64_t fair = n / (3ull * gridDim.x) / WAVE * WAVE;
+    return (uint32_t)min((uint64_t)chunk_max, max((uint64_t)WAVE, fair));
+}
 template <int STACK>
-__global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Pool pl, RenderArgs ra, const float4 *__restrict__ qray,
-                                                                  uint32_t n, unsigned long long *cursor,
+__global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Pool pl, RenderArgs ra, int cur, uint32_t vote_from,
                                                                   unsigned long long *counters, int refill_min, int tri_bias,
-                                                                  uint32_t chunk_rays) {
+                                                                  uint32_t chunk_max) {
     __shared__ uint32_t smem[STACK * WAVE];
+    const uint32_t n = pl.it->n_ext;
+    if (n < vote_from || (uint64_t)blockIdx.x * WAVE >= n) return;          // the one-shot kernel takes small launches
+    const float4 *__restrict__ qray = pl.q_ext_ray[cur];
     const float step = ra.p.step_size;
     TravCounters cnt;
     vote_walk<WAVE, false, false, uint32_t>(
-        bvh, smem + threadIdx.x, n, cursor, refill_min, tri_bias, chunk_rays, cnt,
+        bvh, smem + threadIdx.x, n, pl.qcnt + (size_t)QC_CURSOR_EXT * QC_STRIDE, refill_min, tri_bias, vote_chunk(n, chunk_max), cnt,
         [&](uint64_t idx, NextRay &nx, uint32_t &entry) {
             const float4 qa = qray[2 * (size_t)idx], qb = qray[2 * (size_t)idx + 1];
             entry = (uint32_t)idx;
@@ -281,87 +346,61 @@ __global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Po
             const bool hit = r.best >= 0;
             pl.q_ext_hit[entry] = make_float4(i2f(hit ? HS_HIT : HS_MISS), i2f(r.best), hit ? r.best_t : 0.0f, 1.0f);
         });
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)n);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)n);
 }
 
 // ------------------------------------------------------------------------------------------ connect
-// Bucket b's rays sit at q_sray[b * cap ...]; workgroups are dealt to the buckets in order.
-template <int STACK>
-__global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool pl, ShadowCounts sn,
-                                                              unsigned long long *counters, int bail_lanes) {
-    __shared__ uint32_t smem[STACK * WAVE];
-    uint32_t blk = blockIdx.x, b = 0, n = 0;
-    bool found = false;
+// Bucket b's rays sit at q_sray[b * cap ...]; ray number idx of the launch counts through the buckets laid end to end.
+__device__ __forceinline__ size_t sray_entry(const Pool &pl, const ShadowCounts &sn, uint32_t idx) {
+    uint32_t rem = idx, b = 0;
 #pragma unroll
-    for (int k = 0; k < NSB; ++k) {          // unrolled: the counts stay in scalar registers
-        const uint32_t nb = (sn.n[k] + WAVE - 1) / WAVE;
-        if (!found) { if (blk < nb) { b = k; n = sn.n[k]; found = true; } else blk -= nb; }
-    }
-    const uint32_t j = blk * WAVE + threadIdx.x;
-    if (j < n) {
-        const size_t i = (size_t)b * pl.cap + j;
-        const float4 a = pl.q_sray_a[i], bb = pl.q_sray_b[i];
-        int res;
-        if (bail_lanes > 0) {
-            res = any_hit_or_bail<WAVE>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, bail_lanes);
-        } else {
-            TravCounters tc;
-            res = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc) ? 1 : 0;
-        }
-        if (res < 2) pl.q_sray_occ[i] = (uint32_t)res;          // the answer goes beside the ray, by queue position
-        // the wave's stragglers: one atomic on this wave's retry region, then the ray numbers
-        const uint32_t shard = blockIdx.x % RETRY_SHARDS;
-        const uint32_t pos = wave_append(pl.qcnt + (size_t)(QC_COUNT + shard) * QC_STRIDE, res == 2);
-        if (res == 2) {
-            if (pos < pl.retry_shard_cap) pl.q_retry[(size_t)shard * pl.retry_shard_cap + pos] = (uint32_t)i;
-            else atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT);
-        }
-    }
-    if (threadIdx.x == 0 && blk * WAVE < n) {
-        uint32_t cnt = min((uint32_t)WAVE, n - blk * WAVE);
-        atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)cnt);
-    }
+    for (int q = 0; q < NSB - 1; ++q) if (b == (uint32_t)q && rem >= sn.n[q]) { rem -= sn.n[q]; b = q + 1; }
+    return (size_t)b * pl.cap + rem;
+}
+__device__ __forceinline__ uint64_t sray_total(const ShadowCounts &sn) {
+    uint64_t n = 0;
+#pragma unroll
+    for (int k = 0; k < NSB; ++k) n += sn.n[k];
+    return n;
 }
 
-// Second launch: the rays the first one gave up on, region by region, in full waves, walked to the end.
+// One-shot waves on a fixed grid, for launches too small for the vote-scheduled kernel.
 template <int STACK>
-__global__ __launch_bounds__(WAVE) void render_connect_retry_kernel(DevBVH bvh, Pool pl, unsigned long long *counters) {
+__global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool pl, uint32_t vote_from, unsigned long long *counters) {
     __shared__ uint32_t smem[STACK * WAVE];
-    const uint32_t shard = blockIdx.x % RETRY_SHARDS, k = blockIdx.x / RETRY_SHARDS;
-    const uint32_t n = min((uint32_t)pl.qcnt[(size_t)(QC_COUNT + shard) * QC_STRIDE], pl.retry_shard_cap);
-    const uint32_t j = k * WAVE + threadIdx.x;
-    if (j >= n) return;
-    const size_t i = pl.q_retry[(size_t)shard * pl.retry_shard_cap + j];
-    if (i >= (size_t)pl.cap * (size_t)pl.nshadow) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)ERR_SLOT); return; }
-    const float4 a = pl.q_sray_a[i], bb = pl.q_sray_b[i];
-    TravCounters tc;
-    const bool occ = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc);
-    pl.q_sray_occ[i] = occ ? 1u : 0u;
+    const ShadowCounts sn = pl.it->sray;
+    const uint64_t n = sray_total(sn);
+    if (n >= vote_from) return;
+    for (uint32_t base = blockIdx.x * WAVE; base < n; base += gridDim.x * WAVE) {
+        const uint32_t j = base + threadIdx.x;
+        if (j >= n) continue;
+        const size_t e = sray_entry(pl, sn, j);
+        const float4 a = pl.q_sray_a[e], bb = pl.q_sray_b[e];
+        TravCounters tc;
+        pl.q_sray_occ[e] = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc) ? 1u : 0u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
 }
 
 // connect: persistent waves walking vote-scheduled single steps (vote_walk, trav_device.hpp), shadow rays dealt in
 // chunks from one cursor over the buckets laid end to end (a chunk is nearly always of one kind).
 template <int STACK>
-__global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, Pool pl, ShadowCounts sn, unsigned long long *cursor,
-                                                                   unsigned long long *counters, int refill_min, int tri_bias,
-                                                                   uint32_t chunk_rays) {
+__global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, Pool pl, uint32_t vote_from, unsigned long long *counters,
+                                                                   int refill_min, int tri_bias, uint32_t chunk_max) {
     __shared__ uint32_t smem[STACK * WAVE];
-    uint64_t n = 0;
-#pragma unroll
-    for (int k = 0; k < NSB; ++k) n += sn.n[k];
+    const ShadowCounts sn = pl.it->sray;
+    const uint64_t n = sray_total(sn);
+    if (n < vote_from || (uint64_t)blockIdx.x * WAVE >= n) return;
     TravCounters cnt;
     vote_walk<WAVE, true, false, uint32_t>(
-        bvh, smem + threadIdx.x, n, cursor, refill_min, tri_bias, chunk_rays, cnt,
+        bvh, smem + threadIdx.x, n, pl.qcnt + (size_t)QC_CURSOR * QC_STRIDE, refill_min, tri_bias, vote_chunk(n, chunk_max), cnt,
         [&](uint64_t idx, NextRay &nx, uint32_t &pos) {
-            uint32_t rem = (uint32_t)idx, b = 0;             // bucket b, entry rem
-#pragma unroll
-            for (int q = 0; q < NSB - 1; ++q) if (b == (uint32_t)q && rem >= sn.n[q]) { rem -= sn.n[q]; b = q + 1; }
-            const size_t e = (size_t)b * pl.cap + rem;
+            const size_t e = sray_entry(pl, sn, (uint32_t)idx);
             const float4 a = pl.q_sray_a[e], bb = pl.q_sray_b[e];
             nx.ox = a.x; nx.oy = a.y; nx.oz = a.z; nx.tmax = a.w; nx.dx = bb.x; nx.dy = bb.y; nx.dz = bb.z; pos = (uint32_t)e;
         },
         [&](uint32_t pos, const RayTrav &r) { pl.q_sray_occ[pos] = r.best ? 1u : 0u; });   // the answer goes beside the ray
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
 }
 
 // ------------------------------------------------------------------------------------------ shade
@@ -401,11 +440,13 @@ enum { SRW = 7 };
 __device__ __forceinline__ int stage_word(int k) { return k == 0 ? 0 : SRW * k - 1; }
 constexpr float SKY_RAY_RANGE = 100000.0f;
 
-// Reads the extend queue just traced (entries 0 .. na-1 of buffer `cur`: ray, pending-call state, extend's answer, the
-// parent's shadow terms, all coalesced) and the shadow-wait queue (nb parked frames whose shadow rays connect has
-// answered); writes the next buffers.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, int cur, uint32_t na,
-                                                                                               uint32_t nb, unsigned long long *counters) {
+// Reads the extend queue just traced (entries 0 .. n_ext-1 of buffer `cur`: ray, pending-call state, extend's answer, the
+// parent's shadow terms, all coalesced) and the shadow-wait queue (n_shp parked frames whose shadow rays connect has
+// answered); writes the next buffers.  The grid covers a full pool; workgroups beyond this iteration's work leave.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, int cur,
+                                                                                               unsigned long long *counters) {
+    const uint32_t na = pl.it->n_ext, nb = pl.it->n_shp;
+    if (blockIdx.x * blockDim.x >= na + nb) return;
     __shared__ float s_fw[FRW * 256];
     extern __shared__ float s_ray[];           // (SRW * nshadow - 1) * 256 floats
     const float4 *list_a = pl.q_ext_ray[cur], *list_a_arg = pl.q_ext_arg[cur], *list_a_sh = pl.q_ext_sh[cur];
@@ -959,11 +1000,12 @@ struct RenderState {
     PtBlackHole bh{}; int has_bh = 0;
     // pool (device), sized for (cap, bounces, nlights)
     char *pool_mem = nullptr; size_t pool_bytes = 0;
-    uint32_t pool_cap = 0; int pool_bounces = -2, pool_nlights = -1, pool_lanes = 0;
-    Pool pools[2]{};                     // one per lane (render_core)
-    hipStream_t lane_stream = nullptr;   // lane 1 runs here, lane 0 on the caller's stream
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_trav[2] = {nullptr, nullptr};
-    unsigned long long *h_qc = nullptr;  // pinned, 2 x QC_COUNT * QC_STRIDE words
+    uint32_t pool_cap = 0; int pool_bounces = -2, pool_nlights = -1;
+    Pool pool{};
+    // the host's view of the queue counters: one pinned copy per batch of iterations in flight (render_core)
+    enum { QC_RING = 2 };
+    unsigned long long *h_qc = nullptr;  // pinned, QC_RING x QC_COUNT * QC_STRIDE words
+    hipEvent_t ev_qc[QC_RING] = {nullptr, nullptr};
     float *d_out = nullptr; size_t out_bytes = 0;
     char *d_tiles = nullptr; size_t tiles_bytes = 0;   // tile list of ptmi_render_tiles_dev
     float *d_accum = nullptr; uint32_t *d_counts = nullptr; size_t accum_pix = 0;
@@ -985,10 +1027,7 @@ void free_scene(ptmi_ctx *ctx) {
     void *ptrs[] = {rs->d_uvs, rs->d_tex, rs->d_tex_pixels, rs->d_stri, rs->d_mats, rs->d_emissive, rs->d_lights,
                     rs->d_sky_img, rs->pool_mem, rs->d_out, rs->d_accum, rs->d_counts, rs->d_tiles};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (rs->lane_stream) (void)hipStreamDestroy(rs->lane_stream);
-    if (rs->ev_begin) (void)hipEventDestroy(rs->ev_begin);
-    if (rs->ev_end) (void)hipEventDestroy(rs->ev_end);
-    for (hipEvent_t e : rs->ev_trav) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : rs->ev_qc) if (e) (void)hipEventDestroy(e);
     if (rs->h_qc) (void)hipHostFree(rs->h_qc);
     delete rs;
     ctx->render = nullptr;
@@ -1108,36 +1147,29 @@ static int tracker_words(int bounces) {
 // device bytes one path of the pool takes (records + its share of every queue)
 static uint64_t pool_bytes_per_path(int bounces, int nlights) {
     const uint64_t nframes = (uint64_t)bounces + 1, nshadow = (uint64_t)nlights + 2;
-    // frames + tracker history + shadow slots and shadow-ray queue + extend queue (ray, state: double buffered; answer) +
-    // shadow-wait queue (double buffered) + free list + retry share
-    return 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (32 + 4 + 16 * 4) * nshadow + (32 + 16 * QA) * 2 + 16 + 32 * 2 + 4 + nshadow;
+    // frames + tracker history + shadow-ray queue (ray, answer) and the shadow terms beside both path queues (double
+    // buffered) + extend queue (ray, state: double buffered; answer) + shadow-wait queue (double buffered) + free list
+    return 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (32 + 4 + 16 * 4) * nshadow + (32 + 16 * QA) * 2 + 16 + 32 * 2 + 4;
 }
 
-static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
+static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces) {
     RenderState *rs = ctx->render;
-    if (rs->pool_mem && rs->pool_cap >= cap && rs->pool_bounces == bounces && rs->pool_nlights == (int)rs->nlights &&
-        rs->pool_lanes == lanes)
+    if (rs->pool_mem && rs->pool_cap >= cap && rs->pool_bounces == bounces && rs->pool_nlights == (int)rs->nlights)
         return PTMI_OK;                  // a larger pool of the same shape serves (tiles of different sizes)
     if (rs->pool_mem) { (void)hipFree(rs->pool_mem); rs->pool_mem = nullptr; }
     const int nframes = bounces + 1, nshadow = (int)rs->nlights + 2;
     const int ntrk = tracker_words(bounces);
     const size_t c = cap;
-    struct Off { size_t fr, trk, qs0, qs1, ra, rb, occ, qr0, qr1, qa0, qa1, qh, xs0, xs1, ss0, ss1, free_, cnt, retry; } of[2];
-    // connect launches at most cap * nshadow / 64 + NSB waves
-    const size_t retry_shard_cap = (((size_t)cap * nshadow / WAVE + NSB) / RETRY_SHARDS + 1) * BAIL_MAX;
+    struct Off { size_t fr, trk, qs0, qs1, ra, rb, occ, qr0, qr1, qa0, qa1, qh, xs0, xs1, ss0, ss1, free_, cnt, it; } o;
     size_t off = 0;
-    for (int l = 0; l < lanes; ++l) {
-        Off &o = of[l];
-        o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
-        o.qs0 = carve(off, 32 * c); o.qs1 = carve(off, 32 * c);
-        o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow); o.occ = carve(off, 4 * c * nshadow);
-        o.xs0 = carve(off, 16 * c * nshadow); o.xs1 = carve(off, 16 * c * nshadow);
-        o.ss0 = carve(off, 16 * c * nshadow); o.ss1 = carve(off, 16 * c * nshadow);
-        o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
-        o.qa0 = carve(off, 16 * QA * c); o.qa1 = carve(off, 16 * QA * c); o.qh = carve(off, 16 * c);
-        o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * (QC_COUNT + RETRY_SHARDS + 2) * QC_STRIDE);
-        o.retry = carve(off, 4 * retry_shard_cap * RETRY_SHARDS);
-    }
+    o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
+    o.qs0 = carve(off, 32 * c); o.qs1 = carve(off, 32 * c);
+    o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow); o.occ = carve(off, 4 * c * nshadow);
+    o.xs0 = carve(off, 16 * c * nshadow); o.xs1 = carve(off, 16 * c * nshadow);
+    o.ss0 = carve(off, 16 * c * nshadow); o.ss1 = carve(off, 16 * c * nshadow);
+    o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
+    o.qa0 = carve(off, 16 * QA * c); o.qa1 = carve(off, 16 * QA * c); o.qh = carve(off, 16 * c);
+    o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * QC_COUNT * QC_STRIDE); o.it = carve(off, sizeof(IterArgs));
     if (hipMalloc((void **)&rs->pool_mem, off) != hipSuccess) {
         (void)hipGetLastError();
         rs->pool_mem = nullptr; rs->pool_cap = 0;
@@ -1145,24 +1177,21 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     }
     rs->pool_bytes = off;
     char *b = rs->pool_mem;
-    for (int l = 0; l < lanes; ++l) {
-        const Off &o = of[l];
-        Pool p{};
-        p.cap = cap; p.nframes = nframes; p.nshadow = nshadow; p.ntrk = ntrk;
-        p.fr = (float4 *)(b + o.fr); p.trk = (float *)(b + o.trk);
-        p.q_ext_sh[0] = (float4 *)(b + o.xs0); p.q_ext_sh[1] = (float4 *)(b + o.xs1);
-        p.q_shp_sh[0] = (float4 *)(b + o.ss0); p.q_shp_sh[1] = (float4 *)(b + o.ss1);
-        p.q_sray_occ = (uint32_t *)(b + o.occ);
-        p.q_ext_ray[0] = (float4 *)(b + o.qr0); p.q_ext_ray[1] = (float4 *)(b + o.qr1);
-        p.q_ext_arg[0] = (float4 *)(b + o.qa0); p.q_ext_arg[1] = (float4 *)(b + o.qa1);
-        p.q_ext_hit = (float4 *)(b + o.qh);
-        p.q_shpath[0] = (float4 *)(b + o.qs0); p.q_shpath[1] = (float4 *)(b + o.qs1);
-        p.q_sray_a = (float4 *)(b + o.ra); p.q_sray_b = (float4 *)(b + o.rb);
-        p.q_free = (uint32_t *)(b + o.free_); p.qcnt = (unsigned long long *)(b + o.cnt);
-        p.q_retry = (uint32_t *)(b + o.retry); p.retry_shard_cap = (uint32_t)retry_shard_cap;
-        rs->pools[l] = p;
-    }
-    rs->pool_cap = cap; rs->pool_bounces = bounces; rs->pool_nlights = (int)rs->nlights; rs->pool_lanes = lanes;
+    Pool p{};
+    p.cap = cap; p.nframes = nframes; p.nshadow = nshadow; p.ntrk = ntrk;
+    p.fr = (float4 *)(b + o.fr); p.trk = (float *)(b + o.trk);
+    p.q_ext_sh[0] = (float4 *)(b + o.xs0); p.q_ext_sh[1] = (float4 *)(b + o.xs1);
+    p.q_shp_sh[0] = (float4 *)(b + o.ss0); p.q_shp_sh[1] = (float4 *)(b + o.ss1);
+    p.q_sray_occ = (uint32_t *)(b + o.occ);
+    p.q_ext_ray[0] = (float4 *)(b + o.qr0); p.q_ext_ray[1] = (float4 *)(b + o.qr1);
+    p.q_ext_arg[0] = (float4 *)(b + o.qa0); p.q_ext_arg[1] = (float4 *)(b + o.qa1);
+    p.q_ext_hit = (float4 *)(b + o.qh);
+    p.q_shpath[0] = (float4 *)(b + o.qs0); p.q_shpath[1] = (float4 *)(b + o.qs1);
+    p.q_sray_a = (float4 *)(b + o.ra); p.q_sray_b = (float4 *)(b + o.rb);
+    p.q_free = (uint32_t *)(b + o.free_); p.qcnt = (unsigned long long *)(b + o.cnt);
+    p.it = (IterArgs *)(b + o.it);
+    rs->pool = p;
+    rs->pool_cap = cap; rs->pool_bounces = bounces; rs->pool_nlights = (int)rs->nlights;
     return PTMI_OK;
 }
 
@@ -1170,148 +1199,69 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
 // two ahead), so a launch needs at least 3 * 64 rays per resident wave for every wave to get work at all, and measured
 // (tools/ab_env_tiles.sh) the one-shot kernels stay ahead up to about eight times that: 10 M rays on this chip.  Below
 // the bound the one-shot kernels run (the draining iterations at the end of a call, tiles rendered one per call),
-// above it the vote-scheduled ones with chunks of render_vote_chunk entries.  Returns 0 for "one-shot".
+// above it the vote-scheduled ones with chunks of up to render_vote_chunk entries.  Both kernels are enqueued every
+// iteration and the one the queue length does not belong to leaves at once (the length is only known on the device).
 // PTMI_RENDER_VOTE_MIN overrides the bound (tests force the vote-scheduled kernels at small sizes with 0).
-static uint32_t vote_chunk_for(const ptmi_ctx *ctx, uint64_t nrays, int per_cu) {
+static uint32_t vote_from_for(const ptmi_ctx *ctx, int per_cu) {
     const uint64_t waves = (uint64_t)ctx->num_cus * (uint64_t)per_cu;
     const uint64_t least = ctx->render_vote_min >= 0 ? (uint64_t)ctx->render_vote_min : waves * 3 * WAVE * 8;
-    if (nrays < least || nrays == 0) return 0;
-    const uint64_t fair = nrays / (3 * waves) / WAVE * WAVE;
-    return (uint32_t)std::min<uint64_t>((uint64_t)ctx->render_vote_chunk, std::max<uint64_t>(WAVE, fair));
+    return (uint32_t)std::min<uint64_t>(least, 0xFFFFFFFEull);
 }
+constexpr uint32_t VOTE_NEVER = 0xFFFFFFFFu;
 
+// One iteration of the wavefront loop on queue buffer `cur`, enqueued without knowing its sizes (IterArgs); the grids
+// cover the most paths the call can have in flight (the pool, or all of the call's samples if those are fewer).
 template <int STACK>
-static void launch_render_extend_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, float4 *qray,
-                                   uint32_t n, hipStream_t s) {
+static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, int cur, hipStream_t s) {
+    const uint64_t most = std::min<uint64_t>(pl.cap, ra.total);
+    const unsigned cap_wgs = (unsigned)((most + 255) / 256), cap_waves = (unsigned)((most + WAVE - 1) / WAVE);
+    hipLaunchKernelGGL(iter_prep_kernel, dim3(1), dim3(64), 0, s, pl, cur, (unsigned long long)ra.total, ctx->d_counters);
+    hipLaunchKernelGGL(generate_kernel, dim3(cap_wgs), dim3(256), 0, s, pl, ra, cur);
+    // extend
+    uint32_t vote_from = VOTE_NEVER;
     if (!sc.has_bh && ra.p.max_steps == 1 && ctx->extend_vote) {
         const int per_cu = std::min(ctx->waves_per_cu((const void *)render_extend_vote_kernel<STACK>, WAVE), ctx->persist_waves_per_cu);
-        const uint32_t chunk = vote_chunk_for(ctx, n, per_cu);
-        if (chunk) {
-            const unsigned pgrid = (unsigned)std::min<uint64_t>((n + WAVE - 1) / WAVE, (uint64_t)ctx->num_cus * per_cu);
-            hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, qray, n,
-                               pl.qcnt + (size_t)QC_CURSOR_EXT * QC_STRIDE, ctx->d_counters, ctx->vote_refill_min,
-                               ctx->vote_tri_bias, chunk);
-            return;
-        }
+        vote_from = vote_from_for(ctx, per_cu);
+        const unsigned pgrid = (unsigned)std::min<uint64_t>(cap_waves, (uint64_t)ctx->num_cus * per_cu);
+        hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, cur, vote_from,
+                           ctx->d_counters, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk);
     }
-    if (sc.has_bh)
-        hipLaunchKernelGGL((render_extend_kernel<STACK, true>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
-                           pl, sc, ra, qray, n, ctx->d_counters);
-    else
-        hipLaunchKernelGGL((render_extend_kernel<STACK, false>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, ctx->dev_bvh(),
-                           pl, sc, ra, qray, n, ctx->d_counters);
-}
-static void launch_render_extend(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, float4 *qray,
-                                 uint32_t n, hipStream_t s) {
-    const int dep = ctx->max_depth;      // the LDS stack is as deep as the tree
-    if (dep <= 16) launch_render_extend_t<16>(ctx, pl, sc, ra, qray, n, s);
-    else if (dep <= 24) launch_render_extend_t<24>(ctx, pl, sc, ra, qray, n, s);
-    else if (dep <= 32) launch_render_extend_t<32>(ctx, pl, sc, ra, qray, n, s);
-    else if (dep <= 48) launch_render_extend_t<48>(ctx, pl, sc, ra, qray, n, s);
-    else launch_render_extend_t<64>(ctx, pl, sc, ra, qray, n, s);
-}
-template <int STACK>
-static void launch_render_connect_t(ptmi_ctx *ctx, const Pool &pl, const ShadowCounts &n, hipStream_t s) {
-    unsigned blocks = 0;
-    for (int b = 0; b < NSB; ++b) blocks += (n.n[b] + WAVE - 1) / WAVE;
+    if (vote_from > 0) {
+        const unsigned grid = (unsigned)std::min<uint64_t>(cap_waves, ((uint64_t)vote_from + WAVE - 1) / WAVE);
+        if (sc.has_bh)
+            hipLaunchKernelGGL((render_extend_kernel<STACK, true>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, sc, ra, cur,
+                               vote_from, ctx->d_counters);
+        else
+            hipLaunchKernelGGL((render_extend_kernel<STACK, false>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, sc, ra, cur,
+                               vote_from, ctx->d_counters);
+    }
+    // connect
+    const uint64_t ray_waves = (most * (uint64_t)pl.nshadow + WAVE - 1) / WAVE;
+    vote_from = VOTE_NEVER;
     if (ctx->connect_vote) {
         const int per_cu = std::min(ctx->waves_per_cu((const void *)render_connect_vote_kernel<STACK>, WAVE), ctx->persist_waves_per_cu);
-        uint64_t nrays = 0;
-        for (int b = 0; b < NSB; ++b) nrays += n.n[b];
-        const uint32_t chunk = vote_chunk_for(ctx, nrays, per_cu);
-        if (chunk) {
-            const unsigned pgrid = (unsigned)std::min<uint64_t>(std::max(blocks, 1u), (uint64_t)ctx->num_cus * per_cu);
-            hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n,
-                               pl.qcnt + (size_t)QC_CURSOR * QC_STRIDE, ctx->d_counters, ctx->vote_refill_min, ctx->vote_tri_bias,
-                               chunk);
-            return;
-        }
+        vote_from = vote_from_for(ctx, per_cu);
+        const unsigned pgrid = (unsigned)std::min<uint64_t>(ray_waves, (uint64_t)ctx->num_cus * per_cu);
+        hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, vote_from,
+                           ctx->d_counters, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk);
     }
-    const int bail = std::max(0, std::min((int)BAIL_MAX, ctx->connect_bail_lanes));
-    hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(blocks), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, n, ctx->d_counters, bail);
-    if (bail > 0) {
-        // a region holds at most ceil(blocks / RETRY_SHARDS) * bail rays; workgroups beyond a region's count leave at once
-        const unsigned per_shard = ((blocks + RETRY_SHARDS - 1) / RETRY_SHARDS * (unsigned)bail + WAVE - 1) / WAVE;
-        hipLaunchKernelGGL((render_connect_retry_kernel<STACK>), dim3(per_shard * RETRY_SHARDS), dim3(WAVE), 0, s, ctx->dev_bvh(), pl,
-                           ctx->d_counters);
+    if (vote_from > 0) {
+        const unsigned grid = (unsigned)std::min<uint64_t>(ray_waves, ((uint64_t)vote_from + WAVE - 1) / WAVE);
+        hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, vote_from, ctx->d_counters);
     }
-}
-static void launch_render_connect(ptmi_ctx *ctx, const Pool &pl, const ShadowCounts &n, hipStream_t s) {
-    const int dep = ctx->max_depth;
-    if (dep <= 16) launch_render_connect_t<16>(ctx, pl, n, s);
-    else if (dep <= 24) launch_render_connect_t<24>(ctx, pl, n, s);
-    else if (dep <= 32) launch_render_connect_t<32>(ctx, pl, n, s);
-    else if (dep <= 48) launch_render_connect_t<48>(ctx, pl, n, s);
-    else launch_render_connect_t<64>(ctx, pl, n, s);
-}
-
-// One lane = one path pool with its queues, working through its own range of sample ids on its own stream.
-// Two lanes run side by side, half an iteration apart: shade waits on memory most of the time (2 waves per SIMD,
-// ~25 % VALU busy) while extend and connect are VALU-bound, so a lane's traversal kernels wait (event) for the
-// other lane's traversal kernels and run under the other lane's shade.  The image does not depend on the split
-// (a sample's RNG stream is keyed by pixel and sample number).
-struct Lane {
-    Pool pl;
-    hipStream_t st = nullptr;
-    uint64_t next_sample = 0, end_sample = 0;
-    int cur = 0;
-    uint32_t n_ext = 0, n_shp = 0;
-    ShadowCounts n_srays{};
-    bool inflight = false;
-    hipEvent_t ev_trav = nullptr;        // recorded after this lane's extend + connect
-    bool ev_recorded = false;
-    unsigned long long *hc = nullptr;    // pinned host copy of the queue counters (a pageable copy would block the host)
-};
-
-static int lane_enqueue(ptmi_ctx *ctx, Lane &L, Lane *other, const DevScene &sc, const RenderArgs &ra) {
-    Pool &pl = L.pl;
-    const size_t qc_bytes = (size_t)QC_COUNT * QC_STRIDE * sizeof(unsigned long long);
-    const int cur = L.cur;
-    PTMI_HIP(ctx, hipMemsetAsync(pl.qcnt, 0, qc_bytes + (size_t)(RETRY_SHARDS + 2) * QC_STRIDE * sizeof(unsigned long long), L.st));
-    if (other && other->ev_recorded) PTMI_HIP(ctx, hipStreamWaitEvent(L.st, other->ev_trav, 0));
-    if (L.n_ext) launch_render_extend(ctx, pl, sc, ra, pl.q_ext_ray[cur], L.n_ext, L.st);
-    uint32_t nsr = 0;
-    for (int b = 0; b < NSB; ++b) nsr += L.n_srays.n[b];
-    if (nsr) launch_render_connect(ctx, pl, L.n_srays, L.st);
-    if (other) { PTMI_HIP(ctx, hipEventRecord(L.ev_trav, L.st)); L.ev_recorded = true; }
-    const uint32_t nshade = L.n_ext + L.n_shp;
+    // shade
     const size_t ray_lds = (size_t)(SRW * pl.nshadow - 1) * 256 * sizeof(float);
-    if (ray_lds > (28u << 10))      // beyond the default 64 KB of LDS per workgroup (gfx950 has 160 KB)
-        PTMI_HIP(ctx, hipFuncSetAttribute((const void *)shade_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds));
-    hipLaunchKernelGGL(shade_kernel, dim3((nshade + 255) / 256), dim3(256), ray_lds, L.st, pl, sc, ra, cur, L.n_ext, L.n_shp, ctx->d_counters);
+    hipLaunchKernelGGL(shade_kernel, dim3(cap_wgs), dim3(256), ray_lds, s, pl, sc, ra, cur, ctx->d_counters);
     PTMI_HIP(ctx, hipGetLastError());
-    PTMI_HIP(ctx, hipMemcpyAsync(L.hc, pl.qcnt, qc_bytes, hipMemcpyDeviceToHost, L.st));
-    L.inflight = true;
     return PTMI_OK;
 }
-
-// waits for the lane's iteration, reads its queue counts and re-fills finished slots with fresh samples
-static int lane_finish(ptmi_ctx *ctx, Lane &L, const RenderArgs &ra) {
-    Pool &pl = L.pl;
-    PTMI_HIP(ctx, hipStreamSynchronize(L.st));
-    L.inflight = false;
-    const int nxt = L.cur ^ 1;
-    const uint32_t n_free = (uint32_t)L.hc[QC_FREE * QC_STRIDE];
-    uint32_t ne = (uint32_t)L.hc[(QC_EXT0 + nxt) * QC_STRIDE];
-    L.n_shp = (uint32_t)L.hc[(QC_SHP0 + nxt) * QC_STRIDE];
-    bool bad = ne > pl.cap || L.n_shp > pl.cap || n_free > pl.cap;
-    for (int b = 0; b < NSB; ++b) {
-        L.n_srays.n[b] = (uint32_t)L.hc[(size_t)(QC_SRAY + b) * QC_STRIDE];
-        const uint64_t room = b < NSB - 1 ? (uint64_t)pl.cap : (uint64_t)pl.cap * (uint64_t)std::max(pl.nshadow - (NSB - 1), 0);
-        bad = bad || L.n_srays.n[b] > room;
-    }
-    if (bad) return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: queue counter out of range");
-    if (n_free && L.next_sample < L.end_sample) {
-        const uint32_t ng = (uint32_t)std::min<uint64_t>(n_free, L.end_sample - L.next_sample);
-        hipLaunchKernelGGL(generate_kernel, dim3((ng + 255) / 256), dim3(256), 0, L.st, pl, ra, (const uint32_t *)pl.q_free, ng,
-                           L.next_sample, pl.q_ext_ray[nxt], pl.q_ext_arg[nxt], ne);
-        PTMI_HIP(ctx, hipGetLastError());
-        L.next_sample += ng;
-        ne += ng;
-    }
-    L.n_ext = ne;
-    L.cur = nxt;
-    return PTMI_OK;
+static int enqueue_iteration(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, int cur, hipStream_t s) {
+    const int dep = ctx->max_depth;      // the LDS stack is as deep as the tree
+    if (dep <= 16) return enqueue_iteration_t<16>(ctx, pl, sc, ra, cur, s);
+    if (dep <= 24) return enqueue_iteration_t<24>(ctx, pl, sc, ra, cur, s);
+    if (dep <= 32) return enqueue_iteration_t<32>(ctx, pl, sc, ra, cur, s);
+    if (dep <= 48) return enqueue_iteration_t<48>(ctx, pl, sc, ra, cur, s);
+    return enqueue_iteration_t<64>(ctx, pl, sc, ra, cur, s);
 }
 
 // Renders samples [spp_begin, spp_begin+spp_count) of the rectangle into d_out chunks and accumulates them
@@ -1347,16 +1297,13 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     // (ptmi_render_samples caps a call at 2^28 samples, so the buffer stays bounded)
     if (out_samples_host) spp_chunk = spp_count;
     const uint64_t max_total = npix * spp_chunk;
-    // two lanes of 2^20 paths when there is enough work to keep both busy, else one
-    const int lanes = (ctx->render_lanes >= 2 && max_total >= (1ull << 18)) ? 2 : 1;
-    // Every wavefront iteration costs ~0.3 ms that does not depend on the number of paths (the tails of three kernels
-    // that wait for their longest rays, one host round trip), so the pool is as large as the work and the memory
-    // budget allow: 2 M paths reach 640 Msamples/s on C3, 16 M reach 760 (profiles/r01c/README.md).
+    // Every wavefront iteration costs time that does not depend on the number of paths (the tails of three kernels
+    // that wait for their longest rays), so the pool is as large as the work and the memory budget allow: 2 M paths
+    // reach 640 Msamples/s on C3, 16 M reach 760 (profiles/r01c/README.md).
     const uint64_t path_bytes = pool_bytes_per_path(bounces, (int)rs->nlights);
-    const uint64_t by_targets = 0xFFFFFFFFull / ((uint64_t)(bounces + 1) * (rs->nlights + 2));   // shadow slot ids are 32-bit
+    const uint64_t by_targets = 0xFFFFFFFFull / ((uint64_t)(bounces + 1) * (rs->nlights + 2));   // shadow-ray queue positions are 32-bit
     const uint64_t by_budget = std::min(by_targets, std::max<uint64_t>(1u << 16, ctx->pool_bytes_max / path_bytes));
-    uint32_t cap = (uint32_t)std::min<uint64_t>({(max_total + lanes - 1) / lanes, (uint64_t)ctx->pool_paths / (uint64_t)lanes,
-                                                 by_budget / (uint64_t)lanes});
+    uint32_t cap = (uint32_t)std::min<uint64_t>({max_total, (uint64_t)ctx->pool_paths, by_budget});
     cap = (cap + 255) / 256 * 256;
     // the per-sample output buffer first (its size is fixed by the request), then as large a pool as fits
     if (rs->out_bytes < max_total * 12) {
@@ -1365,17 +1312,20 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         rs->out_bytes = max_total * 12;
     }
     int rc;
-    while ((rc = ensure_pool(ctx, cap, bounces, lanes)) == PTMI_ERR_OOM && cap > (1u << 16))
+    while ((rc = ensure_pool(ctx, cap, bounces)) == PTMI_ERR_OOM && cap > (1u << 16))
         cap = (cap / 2 + 255) / 256 * 256;          // device memory is short (other contexts on this GPU): halve
     if (rc == PTMI_ERR_OOM) return set_err(ctx, PTMI_ERR_OOM, "ptmi_render: out of device memory for the path pool");
     if (rc) return rc;
-    cap = rs->pool_cap;
-    if (!rs->lane_stream) {
-        PTMI_HIP(ctx, hipStreamCreateWithFlags(&rs->lane_stream, hipStreamNonBlocking));
-        PTMI_HIP(ctx, hipEventCreateWithFlags(&rs->ev_begin, hipEventDisableTiming));
-        PTMI_HIP(ctx, hipEventCreateWithFlags(&rs->ev_end, hipEventDisableTiming));
-        for (hipEvent_t &e : rs->ev_trav) PTMI_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        PTMI_HIP(ctx, hipHostMalloc((void **)&rs->h_qc, 2 * QC_COUNT * QC_STRIDE * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!rs->h_qc) {
+        for (hipEvent_t &e : rs->ev_qc) PTMI_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        PTMI_HIP(ctx, hipHostMalloc((void **)&rs->h_qc, RenderState::QC_RING * QC_COUNT * QC_STRIDE * sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    Pool pl = rs->pool;          // a larger pool than asked for may be in place: its queues are laid out for ITS capacity
+    pl.out = rs->d_out;
+    {
+        const size_t ray_lds = (size_t)(SRW * pl.nshadow - 1) * 256 * sizeof(float);
+        if (ray_lds > (28u << 10))      // beyond the default 64 KB of LDS per workgroup (gfx950 has 160 KB)
+            PTMI_HIP(ctx, hipFuncSetAttribute((const void *)shade_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds));
     }
 
     DevScene sc{};
@@ -1393,45 +1343,38 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         ra.tile_first = d_tile_first; ra.tile_rect = d_tile_rect; ra.ntiles = ntiles;
         ra.spp_begin = spp_begin + done; ra.spp_chunk = chunk; ra.total = npix * chunk;
 
-        // lane 1's stream joins the caller's stream here and hands back at the end of the chunk
-        if (lanes > 1) {
-            PTMI_HIP(ctx, hipEventRecord(rs->ev_begin, s));
-            PTMI_HIP(ctx, hipStreamWaitEvent(rs->lane_stream, rs->ev_begin, 0));
-        }
-        Lane L[2];
-        const uint64_t half = lanes > 1 ? (ra.total + 1) / 2 : ra.total;
-        for (int l = 0; l < lanes; ++l) {
-            L[l].pl = rs->pools[l];
-            L[l].pl.out = rs->d_out;
-            L[l].st = l == 0 ? s : rs->lane_stream;
-            L[l].hc = rs->h_qc + (size_t)l * QC_COUNT * QC_STRIDE;
-            L[l].ev_trav = rs->ev_trav[l];
-            L[l].next_sample = l == 0 ? 0 : half;
-            L[l].end_sample = l == 0 ? half : ra.total;
-            // initial fill
-            const uint32_t n0 = (uint32_t)std::min<uint64_t>(cap, L[l].end_sample - L[l].next_sample);
-            if (n0) {
-                hipLaunchKernelGGL(generate_kernel, dim3((n0 + 255) / 256), dim3(256), 0, L[l].st, L[l].pl, ra,
-                                   (const uint32_t *)nullptr, n0, L[l].next_sample, L[l].pl.q_ext_ray[0], L[l].pl.q_ext_arg[0], 0u);
-                PTMI_HIP(ctx, hipGetLastError());
+        // The wavefront loop.  The device sizes every iteration itself (iter_prep_kernel), so the host enqueues
+        // iterations blind, a batch at a time, and looks at the queue counters once per batch -- one batch behind what
+        // it has enqueued, so the GPU never waits for the host.  The batches enqueued after the pool drained are empty
+        // iterations (every kernel leaves at once): at most 2 * iters_per_batch of them.
+        const size_t qc_words = (size_t)QC_COUNT * QC_STRIDE;
+        const uint32_t n0 = (uint32_t)std::min<uint64_t>(pl.cap, ra.total);
+        hipLaunchKernelGGL(iter_init_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, pl, n0);
+        PTMI_HIP(ctx, hipGetLastError());
+        int cur = 0;
+        const int iters_per_batch = std::max(1, ctx->render_batch_iters);
+        auto enqueue_batch = [&](int slot) -> int {
+            for (int k = 0; k < iters_per_batch; ++k) {
+                int r = enqueue_iteration(ctx, pl, sc, ra, cur, s);
+                if (r) return r;
+                cur ^= 1;
             }
-            L[l].next_sample += n0;
-            L[l].n_ext = n0;
-        }
-        for (int l = 0; l < lanes; ++l)
-            if (L[l].n_ext + L[l].n_shp > 0 && (rc = lane_enqueue(ctx, L[l], lanes > 1 ? &L[l ^ 1] : nullptr, sc, ra))) return rc;
-        uint64_t guard = 0;
-        while (L[0].inflight || (lanes > 1 && L[1].inflight)) {
-            if (++guard > 100000000ull) return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: wavefront loop did not terminate");
-            for (int l = 0; l < lanes; ++l) {
-                if (!L[l].inflight) continue;
-                if ((rc = lane_finish(ctx, L[l], ra))) return rc;
-                if (L[l].n_ext + L[l].n_shp > 0 && (rc = lane_enqueue(ctx, L[l], lanes > 1 ? &L[l ^ 1] : nullptr, sc, ra))) return rc;
-            }
-        }
-        if (lanes > 1) {
-            PTMI_HIP(ctx, hipEventRecord(rs->ev_end, rs->lane_stream));
-            PTMI_HIP(ctx, hipStreamWaitEvent(s, rs->ev_end, 0));
+            // the counters as the batch's last shade left them: queue lengths of buffer `cur`, samples handed out
+            PTMI_HIP(ctx, hipMemcpyAsync(rs->h_qc + (size_t)slot * qc_words, pl.qcnt, qc_words * sizeof(unsigned long long),
+                                         hipMemcpyDeviceToHost, s));
+            PTMI_HIP(ctx, hipEventRecord(rs->ev_qc[slot], s));
+            return PTMI_OK;
+        };
+        if ((rc = enqueue_batch(0))) return rc;
+        for (uint64_t batch = 0;; ++batch) {
+            if (batch > 100000000ull) return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: wavefront loop did not terminate");
+            const int slot = (int)(batch % RenderState::QC_RING), ahead = (int)((batch + 1) % RenderState::QC_RING);
+            const int cur_then = cur;                       // the buffer batch `batch` left its queues in
+            if ((rc = enqueue_batch(ahead))) return rc;
+            PTMI_HIP(ctx, hipEventSynchronize(rs->ev_qc[slot]));
+            const unsigned long long *hc = rs->h_qc + (size_t)slot * qc_words;
+            const unsigned long long left = hc[(QC_EXT0 + cur_then) * QC_STRIDE] + hc[(QC_SHP0 + cur_then) * QC_STRIDE];
+            if (left == 0 && hc[QC_NEXT * QC_STRIDE] >= ra.total) break;
         }
         {   // integrator self-checks (ERR_*): any bit set means a path record was corrupt
             unsigned long long hcnt[CNT_WORDS];

@@ -606,54 +606,6 @@ __device__ __forceinline__ bool any_hit_impl(const DevBVH &bvh, uint32_t *stack_
     }
 #endif
 }
-// The same walk for a wave that hands its stragglers on: when no more than `bail_lanes` lanes of the wave are still
-// walking, they give up (result 2) and their rays are traced again from the root by a second launch, packed into
-// full waves (the answer of an any-hit walk is a pure function of the ray).  0 = free, 1 = occluded, 2 = gave up.
-template <int BLOCK, bool EXACT>
-__device__ __forceinline__ int any_hit_or_bail_impl(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
-                                                    float dx, float dy, float dz, float ix, float iy, float iz, float step,
-                                                    int bail_lanes) {
-    LdsStack<BLOCK> st{stack_base};
-    uint32_t cur = bvh.root_ref;
-    for (;;) {
-        if (__popcll(__ballot(1)) <= bail_lanes) return 2;
-        while (!(cur & D_REF_LEAF_BIT)) {
-            const float4 *p = bvh.nodes + (size_t)cur * 4;
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-            float d1 = slab_sel<EXACT>(q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, ox, oy, oz, ix, iy, iz, step);
-            float d2 = slab_sel<EXACT>(q0.z, q1.z, q2.z, q0.w, q1.w, q2.w, ox, oy, oz, ix, iy, iz, step);
-            uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
-            bool h1 = d1 < step, h2 = d2 < step;
-            if (h1 && h2) {
-                if (d1 < d2) { st.push(r1); cur = r0; } else { st.push(r0); cur = r1; }
-            } else if (h1) cur = r0;
-            else if (h2) cur = r1;
-            else cur = st.empty() ? D_REF_DONE : st.pop();
-        }
-        if (cur == D_REF_DONE) return 0;
-        {
-            const uint32_t first = cur & 0x7FFFFFFFu;
-            const float4 *p = bvh.tris + (size_t)first * 3;
-            for (;;) {
-                const float4 r0 = p[0], r1 = p[1], r2 = p[2];
-                if (shadow_triangle(ox, oy, oz, dx, dy, dz, step, r1.z, r1.w, r2.x, r0.x, r0.z, r1.x, r0.y, r0.w, r1.y))
-                    return 1;
-                if (__float_as_uint(r2.z) == 0u) break;
-                p += 3;
-            }
-        }
-        cur = st.empty() ? D_REF_DONE : st.pop();
-    }
-}
-template <int BLOCK>
-__device__ __forceinline__ int any_hit_or_bail(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
-                                               float dx, float dy, float dz, float step, int bail_lanes) {
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    if (__any(ray_needs_exact(bvh, ox, oy, oz, ix, iy, iz, step)))
-        return any_hit_or_bail_impl<BLOCK, true>(bvh, stack_base, ox, oy, oz, dx, dy, dz, ix, iy, iz, step, bail_lanes);
-    return any_hit_or_bail_impl<BLOCK, false>(bvh, stack_base, ox, oy, oz, dx, dy, dz, ix, iy, iz, step, bail_lanes);
-}
-
 template <int BLOCK, bool COUNT>
 __device__ __forceinline__ bool any_hit(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
                                         float dx, float dy, float dz, float step, TravCounters &cnt) {

@@ -300,20 +300,22 @@ def test_tiles_in_one_call(gpu_ctx):
 
 
 def test_traversal_kernel_forms_agree_bit_for_bit(monkeypatch):
-    """connect has two forms, chosen when a context is created: the vote-scheduled persistent kernel (default) and
-    one-shot waves (PTMI_CONNECT_VOTE=0) that hand their last walking lanes to a second launch (PTMI_CONNECT_BAIL lanes,
-    0 = never); extend has a vote-scheduled form too (PTMI_EXTEND_VOTE, by default chosen by tree size).  The answer of
-    a walk is a pure function of the ray, so all of them give the same sums bit for bit.
+    """connect and extend each have two forms, chosen on the device by the length of the queue: the vote-scheduled
+    persistent kernel for long queues and one-shot waves for short ones (PTMI_CONNECT_VOTE=0 / PTMI_EXTEND_VOTE=0 switch
+    the vote-scheduled form off, PTMI_RENDER_VOTE_MIN moves the bound).  The answer of a walk is a pure function of the
+    ray, so all of them give the same sums bit for bit -- and so does any number of iterations enqueued between two
+    looks at the queue counters (PTMI_RENDER_BATCH_ITERS).
     (test_many_lights runs the shared last bucket through the default form against the oracle.)"""
     from pathtrace_amd import Context
     sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
     p = make_params(96, 64, bounces=2, seed=9)
     frames = []
-    # launches this small run the one-shot kernels unless PTMI_RENDER_VOTE_MIN=0 forces the vote-scheduled ones
-    for vote, bail, ext, vmin in ((None, None, None, "0"), ("0", "0", "0", "0"), ("0", None, "1", "0"), ("0", "5", None, "0"),
-                                  (None, None, None, None), ("1", "0", "1", "0")):
-        for var, val in (("PTMI_CONNECT_VOTE", vote), ("PTMI_CONNECT_BAIL", bail), ("PTMI_EXTEND_VOTE", ext),
-                         ("PTMI_RENDER_VOTE_MIN", vmin)):
+    # launches this small run the one-shot kernels unless PTMI_RENDER_VOTE_MIN=0 forces the vote-scheduled ones;
+    # 20000 puts the bound inside this render's range of queue lengths (30 720 samples at the start, a tail at the end)
+    for vote, ext, vmin, batch in ((None, None, "0", None), ("0", "0", "0", None), ("0", "1", "0", "1"), (None, None, "20000", "7"),
+                                   (None, None, None, None), ("1", "0", "0", "2")):
+        for var, val in (("PTMI_CONNECT_VOTE", vote), ("PTMI_EXTEND_VOTE", ext), ("PTMI_RENDER_VOTE_MIN", vmin),
+                         ("PTMI_RENDER_BATCH_ITERS", batch)):
             if val is None:
                 monkeypatch.delenv(var, raising=False)
             else:
