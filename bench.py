@@ -20,7 +20,7 @@ Prints ONE JSON line on rank 0.  Besides the contract's keys it carries
                         1 only says the tree is served from cache) and `hbm_frac_counter` (fabric bytes measured in
                         this run with rocprofv3 PMC passes over a child process / time / 8 TB/s); `traffic` = those
                         fabric bytes per launch.
-  roofline_hbm_resident the same for a second leg whose tree (10 M triangles, 0.86 GB) does not fit the 256 MiB
+  roofline_hbm_resident the same for a second leg whose tree (10 M triangles, 0.67 GB) does not fit the 256 MiB
                         Infinity Cache (N=1 only).
   cpu_baseline          the C restatement of the Go reference (the Go code cannot be built here) on the host cores:
                         CheckIntersection single-threaded and on all cores of this job's CPU share, on a bounded
@@ -461,6 +461,16 @@ def render_leg(args, rank, world, dist, dev, torch):
         q[0] = mx[0]
     q = q.cpu().tolist()
     complete = bool((cnt == spp).all().item()) if rank == 0 else True
+    if world == 1:
+        how = "single GPU"
+    else:
+        how = f"blocks of 8 rows round-robin over {world} ranks, one render call per rank + "
+        if comm.kind == "rccl":
+            how += "RCCL ncclReduce behind the C ABI (ptmi_render_sharded)"
+        elif os.environ.get("PTMI_BENCH_REHEARSE") == "1":
+            how += "host-staged gloo reduce (rehearsal)"
+        else:
+            how += f"torch.distributed reduce (the C ABI's communicator was not available: {comm.note})"
     if comm is not None:
         comm.close()
     return {"metric": "samples/s, full multi-bounce integrator", "value": round(W * H * spp / q[0] / 1e6, 2),
@@ -468,8 +478,7 @@ def render_leg(args, rank, world, dist, dev, torch):
             "config": {"workload": "C3: blob + glass spheres + emissive quad + mirror sphere, gradient sky + sun "
                                    "(BASELINE.json configs[2])", "width": W, "height": H, "spp": spp, "bounces": 2,
                        "triangles": int(sc.tris.shape[0]),
-                       "sharding": "single GPU" if world == 1 else f"blocks of 8 rows round-robin over {world} ranks, one render call per rank + "
-                                                                    f"{'RCCL ncclReduce behind the C ABI (ptmi_render_sharded)' if comm is not None and comm.kind == 'rccl' else 'host-staged gloo reduce (rehearsal)'}"},
+                       "sharding": how},
             "closest_hit_Mqueries_per_s": round(q[1] / q[0] / 1e6, 1), "any_hit_Mqueries_per_s": round(q[2] / q[0] / 1e6, 1),
             "diffuse_events_M_per_s": round(q[3] / q[0] / 1e6, 1), "frame_complete": complete}
 
@@ -492,6 +501,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU time budget of the closest-hit baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--render-timeout", type=float, default=240.0, help="N > 1: seconds after which a stuck render leg is given up")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -622,9 +632,31 @@ def main():
         del wl2
         torch.cuda.empty_cache()
 
+    # The primary figure is complete here.  With N > 1 the render leg enters collectives (communicator set-up, the frame
+    # reduce): if a rank fails or hangs there, the others would wait for ever and the whole line would be lost, so a
+    # watchdog per rank ends the process after --render-timeout seconds; rank 0 prints the line without the render leg.
+    state = {"printed": False}
+    watchdog = None
+    if world > 1:
+        import threading
+
+        def give_up():
+            if rank == 0 and not state["printed"]:
+                out["render"] = {"error": f"the render leg did not finish within {args.render_timeout:.0f} s (a rank failed or a "
+                                          "collective hung); the primary figure above is unaffected"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.render_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
     render = None
     if not args.no_render:
-        render = render_leg(args, rank, world, dist, dev, torch)
+        try:
+            render = render_leg(args, rank, world, dist, dev, torch)
+        except Exception as e:               # noqa: BLE001 -- reported in the line, the primary figure stands
+            if world == 1:
+                raise
+            render = {"error": f"rank {rank}: {type(e).__name__}: {e}"}
     if rank == 0:
         if render is not None:
             out["render"] = render
@@ -632,9 +664,12 @@ def main():
             tb = cpu_tile_renderer_baseline(args, dev)
             out["cpu_baseline"]["tile_renderer"] = tb
         print(json.dumps(out), flush=True)
+        state["printed"] = True
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 if __name__ == "__main__":

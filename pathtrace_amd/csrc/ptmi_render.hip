@@ -12,9 +12,10 @@
 //   connect  : any-hit for the shadow-ray queue (QuickCheckIntersection, linear_bvh.go:202)
 //   accumulate : per-pixel sums in sample order (Pixel.AddSample, renderer.go:59-61)
 // Queues are compacted with one atomic per workgroup (ballot + popcount per wave, summed in LDS); finished paths
-// are re-filled with fresh samples so the pool stays full.  Path state is an array of structures: a 128-byte header
-// line and 128-byte frame lines per path (queue order is arbitrary, so per-path records move whole lines where a
-// [field][slot] layout cost one sector per word).
+// are re-filled with fresh samples so the pool stays full.  A path's live state travels with its queue entry
+// (coalesced); what stays behind per path are 128-byte frame lines, one per parked TraceRay invocation (queue order
+// is arbitrary, so per-path records move whole lines where a [field][slot] layout cost one sector per word;
+// DESIGN.md section 3).  The loop itself is driven from the device (IterArgs below).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -24,12 +25,12 @@
 
 using namespace ptmi;
 
-// Timing-only ablation builds (tools/build_variant.sh <name> -DPTMI_ABLATE=<bits>): each bit removes one piece of shade's
-// memory traffic to price it; the images of such builds are wrong.  0 in the product.
-#ifndef PTMI_ABLATE
-#define PTMI_ABLATE 0
+// Experiment build (tools/build_variant.sh regs -DPTMI_FRAME_REGS=1): shade keeps the top frame in 31 registers instead
+// of LDS.  Not the product (the kernel cannot afford the registers); kept to reproduce round 1's "a frame word changes
+// between a reload and its use" report, see DESIGN.md section 4.
+#ifndef PTMI_FRAME_REGS
+#define PTMI_FRAME_REGS 0
 #endif
-#define ABL(bit) ((PTMI_ABLATE) & (bit))
 
 namespace {
 
@@ -39,9 +40,9 @@ constexpr int WAVE = 64;
 __device__ __forceinline__ void lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---- frame fields (one frame per TraceRay invocation on the explicit recursion stack) ----------
-// A frame is 32 words = one 128-byte line, stored per path ([slot][depth][32]): shade loads the top
-// frame with eight 16-byte loads into registers, works on it there and writes it back when the path
-// parks (queue order is arbitrary, so a [field][slot] layout costs one 32/64-byte sector per word).
+// A frame is 32 words = one 128-byte line, stored per path ([slot][depth][32]): shade builds the top frame in
+// LDS ([word][thread]) from the queue entry of a pending call, or loads it there with eight 16-byte loads when a
+// child returns to it, works on it there and writes it back only when the path parks under a child.
 enum {
     F_BB = 0,                                                              // bounces | bounceIndex << 16 | flags << 24 (inputs of TraceRay, :15)
     F_SP = 1,                                                              // sample counter of the GI / reflection loop | phase << 24
@@ -518,7 +519,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         // The top frame lives in LDS, [word][thread] (conflict-free): it is read and written all over the state
         // machine below, and 32 more loop-carried registers per lane are what this kernel cannot afford.
         const uint32_t tid = threadIdx.x;
+#if PTMI_FRAME_REGS
+        float fw_reg[FRW];
+#define FW(field) fw_reg[(field)]
+#else
 #define FW(field) s_fw[(field) * 256 + tid]
+#endif
         auto load_frame = [&](int dep) {
             const float4 *f = frames + (size_t)dep * 8;
 #pragma unroll
@@ -899,14 +905,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         // [queue][wave] counts, then bases (ext, shadow paths, free, NSB ray buckets), in the frame area: wave w uses
         // words of its OWN threads' columns (frame word 0 of threads 64 w + q), which are dead now that the whole wave
         // has left the state machine; other waves may still be in theirs
-        uint32_t *s_q = (uint32_t *)s_fw;
-#define SQ(q, w) s_q[(w) * 64 + (q)]
+        // (kept as float bit patterns: one access type per LDS word, no type-punned pointer for the optimiser to reorder around)
+#define SQ(q, w) f2u(s_fw[(w) * 64 + (q)])
+#define SQ_SET(q, w, v) (s_fw[(w) * 64 + (q)] = u2f(v))
         if (lane == 63) {
-            SQ(0, wv) = (uint32_t)__popcll(m_ext); SQ(1, wv) = (uint32_t)__popcll(m_shp);
-            SQ(2, wv) = (uint32_t)__popcll(m_fin);
+            SQ_SET(0, wv, (uint32_t)__popcll(m_ext)); SQ_SET(1, wv, (uint32_t)__popcll(m_shp));
+            SQ_SET(2, wv, (uint32_t)__popcll(m_fin));
 #pragma unroll
-            for (int b = 0; b < NSB - 1; ++b) SQ(3 + b, wv) = (uint32_t)__popcll(m_ray[b]);
-            SQ(3 + NSB - 1, wv) = pl.nshadow >= NSB ? incl : 0u;
+            for (int b = 0; b < NSB - 1; ++b) SQ_SET(3 + b, wv, (uint32_t)__popcll(m_ray[b]));
+            SQ_SET(3 + NSB - 1, wv, pl.nshadow >= NSB ? incl : 0u);
         }
         lds_barrier();
         if (threadIdx.x < 3 + NSB) {
@@ -916,7 +923,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             unsigned long long *ctr = q == 0 ? qc_ext_next : q == 1 ? qc_shp_next : &pl.qcnt[(size_t)(QC_FREE + (q - 2)) * QC_STRIDE];
             uint32_t base = 0;
             if (total) base = (uint32_t)atomicAdd(ctr, (unsigned long long)total);
-            SQ(q, 0) = base; SQ(q, 1) = base + c0; SQ(q, 2) = base + c0 + c1; SQ(q, 3) = base + c0 + c1 + c2;
+            SQ_SET(q, 0, base); SQ_SET(q, 1, base + c0); SQ_SET(q, 2, base + c0 + c1); SQ_SET(q, 3, base + c0 + c1 + c2);
             if (q == 2 && total) atomicAdd(&counter_shard(counters)[CNT_SAMPLES], (unsigned long long)total);
         }
         if (lane == 0 && diffuse_events) atomicAdd(&counter_shard(counters)[CNT_DIFFUSE], (unsigned long long)diffuse_events);
@@ -960,6 +967,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
         }
 #undef SQ
+#undef SQ_SET
     }
 }
 

@@ -58,6 +58,7 @@ class DistComm:
     """Framebuffer reduce over torch.distributed -- gloo on the CPU (tests) or any object with the same `reduce`
     (bench.py's host-staged rehearsal).  The product's GPU path uses PtmiComm."""
     kind = "dist"
+    note = ""
 
     def __init__(self, dist, rank, world, group=None):
         self.dist, self.rank, self.world, self.group = dist, rank, world, group
@@ -75,6 +76,7 @@ class PtmiComm:
     """The C ABI's RCCL communicator of a context (include/ptmi.h "multi-GPU"): one rank per process.  `unique_id` is
     the 128 bytes rank 0 got from PtmiComm.unique_id(), handed over by any channel the host has."""
     kind = "rccl"
+    note = ""
 
     def __init__(self, ctx, rank, world, unique_id: bytes):
         import ctypes as C
@@ -111,17 +113,48 @@ class PtmiComm:
 def make_comm(renderer, rank, world, dist, dev, rehearse=False):
     """The communicator of this rank's context.  The RCCL unique id travels over the process group the launcher set up
     (torch.distributed: a 128-byte broadcast); with rehearse=True (all ranks on one GPU, which RCCL refuses) the reduce
-    goes through the host instead."""
+    goes through the host instead.
+
+    The ranks agree on the outcome: if any of them cannot reach RCCL through the C ABI (library not found, init refused),
+    ALL of them fall back to a DistComm over the launcher's process group -- a rank that went ahead alone would wait in
+    ncclCommInitRank for ever.  The reason is kept in `.note`."""
     if world <= 1:
         return None
     if rehearse:
         return DistComm(dist, rank, world)
     import torch
+
+    def all_ok(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def fallback(why):
+        c = DistComm(dist, rank, world)
+        c.note = why
+        return c
+
+    why, my_id = "", None
+    try:                                   # loads and binds RCCL in this process; only rank 0's id is used
+        my_id = PtmiComm.unique_id()
+    except Exception as e:                 # noqa: BLE001 -- whatever it is, the ranks have to agree on it
+        why = f"rank {rank}: {e}"
+    if not all_ok(my_id is not None):
+        return fallback(why or "another rank could not load RCCL through the C ABI")
     uid = torch.zeros(128, dtype=torch.uint8, device=dev)
     if rank == 0:
-        uid.copy_(torch.frombuffer(bytearray(PtmiComm.unique_id()), dtype=torch.uint8))
+        uid.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
     dist.broadcast(uid, src=0)
-    return PtmiComm(renderer.ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
+    comm = None
+    try:
+        comm = PtmiComm(renderer.ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
+    except Exception as e:                 # noqa: BLE001
+        why = f"rank {rank}: {e}"
+    if not all_ok(comm is not None):
+        if comm is not None:
+            comm.close()
+        return fallback(why or "another rank could not initialise its RCCL communicator")
+    return comm
 
 
 def render_frame_sharded(renderer, comm, accum, counts, params, camera, spp, row_block=8, root=0, stream=None, spp_begin=0):

@@ -24,9 +24,14 @@ for name, calls in (("whole frame, one call", [[(0, 0, W, H)]]), ("4x4 split, on
                     ("4x4 split, one call for the 16 tiles", [split]), ("64x64 tiles, one call per tile", [[t] for t in small]),
                     ("64x64 tiles, one call for the 510 tiles", [small])):
     acc.zero_(); cnt.zero_(); torch.cuda.synchronize(); t0 = time.time()
+    per_call = []
     for tiles in calls:
+        t1 = time.time()
         if len(tiles) == 1: rr(acc, cnt, tiles[0], 0, spp)
         else: r.render_tiles_device(acc, cnt, p, sc.camera, tiles, spp=spp, stream=st)
+        per_call.append(time.time() - t1)           # the render calls return when the region is done
     torch.cuda.synchronize(); dt = time.time() - t0
     assert bool((cnt == spp).all())
-    print(f"{name}: {len(calls)} calls, {W * H * spp / dt / 1e6:.1f} Msamples/s")
+    per_call.sort()
+    print(f"{name}: {len(calls)} calls, {W * H * spp / dt / 1e6:.1f} Msamples/s; per call min / median / max "
+          f"{per_call[0] * 1e3:.2f} / {per_call[len(per_call) // 2] * 1e3:.2f} / {per_call[-1] * 1e3:.2f} ms")
