@@ -236,6 +236,7 @@ extern "C" int ptmi_create(int device, ptmi_ctx **out) {
         if (const char *v = getenv("PTMI_CONNECT_VOTE")) ctx->connect_vote = atoi(v);
         if (const char *v = getenv("PTMI_SEGMENT_SHORTCUT")) ctx->segment_shortcut = atoi(v);
         if (const char *v = getenv("PTMI_RENDER_VOTE_MIN")) ctx->render_vote_min = atoll(v);
+        if (const char *v = getenv("PTMI_RENDER_VOTE_REFILL_MIN")) ctx->render_vote_refill_min = std::max(1, std::min(64, atoi(v)));
         if (const char *v = getenv("PTMI_RENDER_VOTE_CHUNK")) ctx->render_vote_chunk = std::max(64, atoi(v) / 64 * 64);
         if (const char *v = getenv("PTMI_EXTEND_VOTE")) ctx->extend_vote = atoi(v);
         if (const char *v = getenv("PTMI_CHUNK_MSAMPLES")) ctx->chunk_msamples = std::max(1, std::min(1024, atoi(v)));

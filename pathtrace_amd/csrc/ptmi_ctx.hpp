@@ -69,6 +69,7 @@ struct ptmi_ctx {
     int extend_vote = 1;                // extend (straight rays, one segment per call) as a vote-scheduled persistent kernel (0: one-shot)
     long long render_vote_min = -1;     // fewest rays a vote-scheduled launch of the integrator takes (-1: three chunks per resident wave)
     int render_vote_chunk = 256;        // queue entries reserved per cursor atomic in the integrator's vote-scheduled kernels
+    int render_vote_refill_min = 32;    // ... and idle lanes that trigger a refill there (the batch kernels: vote_refill_min)
     int segment_shortcut = 1;           // the curved march skips the walk for segments far outside the tree's tight box
     int connect_vote = 1;               // connect as a vote-scheduled persistent kernel (0: one-shot waves + hand-over)
     int render_batch_iters = 2;         // wavefront iterations enqueued between two looks at the queue counters (render_core)
