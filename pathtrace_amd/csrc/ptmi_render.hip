@@ -126,7 +126,22 @@ struct RenderArgs {
     const uint32_t *tile_first; const int4 *tile_rect; uint32_t ntiles;
     uint32_t spp_begin, spp_chunk;       // this batch covers samples [spp_begin, spp_begin+spp_chunk) of every pixel
     uint64_t total;                      // w*h*spp_chunk
+    // The samples of a pass are dealt to `nlanes` independent wavefront loops in blocks of LANE_BLOCK sample ids, round
+    // robin: sample j of lane `lane` is sample id ((j / LANE_BLOCK) * nlanes + lane) * LANE_BLOCK + j % LANE_BLOCK.
+    uint32_t lane, nlanes;
 };
+enum { LANE_BLOCK_LOG2 = 16, LANE_BLOCK = 1 << LANE_BLOCK_LOG2 };
+__host__ __device__ inline uint64_t lane_sample_id(uint64_t j, uint32_t lane, uint32_t nlanes) {
+    return nlanes <= 1 ? j : ((((j >> LANE_BLOCK_LOG2) * nlanes + lane) << LANE_BLOCK_LOG2) | (j & (LANE_BLOCK - 1)));
+}
+// how many of the sample ids 0 .. total-1 belong to `lane` (only the last block can be short, and it is its lane's last)
+static uint64_t lane_sample_count(uint64_t total, uint32_t lane, uint32_t nlanes) {
+    if (nlanes <= 1) return total;
+    const uint64_t full = total >> LANE_BLOCK_LOG2, rest = total & (LANE_BLOCK - 1);
+    uint64_t n = (full / nlanes + (lane < full % nlanes ? 1 : 0)) << LANE_BLOCK_LOG2;
+    if (rest && full % nlanes == lane) n += rest;
+    return n;
+}
 
 // Path pool: array of structures per slot.
 struct Pool {
@@ -195,7 +210,8 @@ __global__ __launch_bounds__(256) void iter_init_kernel(Pool pl, uint32_t n0) {
     if (blockIdx.x == 0 && threadIdx.x < QC_COUNT) pl.qcnt[(size_t)threadIdx.x * QC_STRIDE] = threadIdx.x == QC_FREE ? n0 : 0ull;
 }
 
-// Start of an iteration on queue buffer `cur` (see IterArgs).  One thread: a dozen counters.
+// Start of an iteration on queue buffer `cur` (see IterArgs).  One thread: a dozen counters.  `total` = the number
+// of samples of this loop (its lane's share of the pass).
 __global__ void iter_prep_kernel(Pool pl, int cur, unsigned long long total, unsigned long long *counters) {
     if (blockIdx.x || threadIdx.x) return;
     auto qc = [&](int w) -> unsigned long long & { return pl.qcnt[(size_t)w * QC_STRIDE]; };
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, i
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t slot = pl.q_free[i];
-        const uint32_t sid = (uint32_t)first_sample + i;                       // total < 2^32/3 (render_core)
+        const uint32_t sid = (uint32_t)lane_sample_id(first_sample + i, ra.lane, ra.nlanes);   // total < 2^32/3 (render_core)
         const uint32_t pix = sid / ra.spp_chunk, smp = sid % ra.spp_chunk;
         int X, Y;
         region_pixel(ra, pix, X, Y);
@@ -1013,12 +1029,14 @@ struct RenderState {
     PtBlackHole bh{}; int has_bh = 0;
     // pool (device), sized for (cap, bounces, nlights)
     char *pool_mem = nullptr; size_t pool_bytes = 0;
-    uint32_t pool_cap = 0; int pool_bounces = -2, pool_nlights = -1;
-    Pool pool{};
-    // the host's view of the queue counters: one pinned copy per batch of iterations in flight (render_core)
-    enum { QC_RING = 2 };
-    unsigned long long *h_qc = nullptr;  // pinned, QC_RING x QC_COUNT * QC_STRIDE words
-    hipEvent_t ev_qc[QC_RING] = {nullptr, nullptr};
+    uint32_t pool_cap = 0; int pool_bounces = -2, pool_nlights = -1, pool_lanes = 0;
+    enum { MAX_LANES = 2, QC_RING = 2 };
+    Pool pools[MAX_LANES]{};             // one per lane (render_core)
+    hipStream_t lane_stream = nullptr;   // lane 1 runs here, lane 0 on the caller's stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // the host's view of the queue counters: per lane one pinned copy per batch of iterations in flight (render_core)
+    unsigned long long *h_qc = nullptr;  // pinned, MAX_LANES x QC_RING x QC_COUNT * QC_STRIDE words
+    hipEvent_t ev_qc[MAX_LANES][QC_RING] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float *d_out = nullptr; size_t out_bytes = 0;
     char *d_tiles = nullptr; size_t tiles_bytes = 0;   // tile list of ptmi_render_tiles_dev
     float *d_accum = nullptr; uint32_t *d_counts = nullptr; size_t accum_pix = 0;
@@ -1040,7 +1058,9 @@ void free_scene(ptmi_ctx *ctx) {
     void *ptrs[] = {rs->d_uvs, rs->d_tex, rs->d_tex_pixels, rs->d_stri, rs->d_mats, rs->d_emissive, rs->d_lights,
                     rs->d_sky_img, rs->pool_mem, rs->d_out, rs->d_accum, rs->d_counts, rs->d_tiles};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (hipEvent_t e : rs->ev_qc) if (e) (void)hipEventDestroy(e);
+    for (auto &lane : rs->ev_qc) for (hipEvent_t e : lane) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {rs->ev_fork, rs->ev_join}) if (e) (void)hipEventDestroy(e);
+    if (rs->lane_stream) (void)hipStreamDestroy(rs->lane_stream);
     if (rs->h_qc) (void)hipHostFree(rs->h_qc);
     delete rs;
     ctx->render = nullptr;
@@ -1165,24 +1185,28 @@ static uint64_t pool_bytes_per_path(int bounces, int nlights) {
     return 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (32 + 4 + 16 * 4) * nshadow + (32 + 16 * QA) * 2 + 16 + 32 * 2 + 4;
 }
 
-static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces) {
+static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
     RenderState *rs = ctx->render;
-    if (rs->pool_mem && rs->pool_cap >= cap && rs->pool_bounces == bounces && rs->pool_nlights == (int)rs->nlights)
+    if (rs->pool_mem && rs->pool_cap >= cap && rs->pool_bounces == bounces && rs->pool_nlights == (int)rs->nlights &&
+        rs->pool_lanes >= lanes)
         return PTMI_OK;                  // a larger pool of the same shape serves (tiles of different sizes)
     if (rs->pool_mem) { (void)hipFree(rs->pool_mem); rs->pool_mem = nullptr; }
     const int nframes = bounces + 1, nshadow = (int)rs->nlights + 2;
     const int ntrk = tracker_words(bounces);
     const size_t c = cap;
-    struct Off { size_t fr, trk, qs0, qs1, ra, rb, occ, qr0, qr1, qa0, qa1, qh, xs0, xs1, ss0, ss1, free_, cnt, it; } o;
+    struct Off { size_t fr, trk, qs0, qs1, ra, rb, occ, qr0, qr1, qa0, qa1, qh, xs0, xs1, ss0, ss1, free_, cnt, it; } of[RenderState::MAX_LANES];
     size_t off = 0;
-    o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
-    o.qs0 = carve(off, 32 * c); o.qs1 = carve(off, 32 * c);
-    o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow); o.occ = carve(off, 4 * c * nshadow);
-    o.xs0 = carve(off, 16 * c * nshadow); o.xs1 = carve(off, 16 * c * nshadow);
-    o.ss0 = carve(off, 16 * c * nshadow); o.ss1 = carve(off, 16 * c * nshadow);
-    o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
-    o.qa0 = carve(off, 16 * QA * c); o.qa1 = carve(off, 16 * QA * c); o.qh = carve(off, 16 * c);
-    o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * QC_COUNT * QC_STRIDE); o.it = carve(off, sizeof(IterArgs));
+    for (int l = 0; l < lanes; ++l) {
+        Off &o = of[l];
+        o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
+        o.qs0 = carve(off, 32 * c); o.qs1 = carve(off, 32 * c);
+        o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow); o.occ = carve(off, 4 * c * nshadow);
+        o.xs0 = carve(off, 16 * c * nshadow); o.xs1 = carve(off, 16 * c * nshadow);
+        o.ss0 = carve(off, 16 * c * nshadow); o.ss1 = carve(off, 16 * c * nshadow);
+        o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
+        o.qa0 = carve(off, 16 * QA * c); o.qa1 = carve(off, 16 * QA * c); o.qh = carve(off, 16 * c);
+        o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * QC_COUNT * QC_STRIDE); o.it = carve(off, sizeof(IterArgs));
+    }
     if (hipMalloc((void **)&rs->pool_mem, off) != hipSuccess) {
         (void)hipGetLastError();
         rs->pool_mem = nullptr; rs->pool_cap = 0;
@@ -1190,21 +1214,24 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces) {
     }
     rs->pool_bytes = off;
     char *b = rs->pool_mem;
-    Pool p{};
-    p.cap = cap; p.nframes = nframes; p.nshadow = nshadow; p.ntrk = ntrk;
-    p.fr = (float4 *)(b + o.fr); p.trk = (float *)(b + o.trk);
-    p.q_ext_sh[0] = (float4 *)(b + o.xs0); p.q_ext_sh[1] = (float4 *)(b + o.xs1);
-    p.q_shp_sh[0] = (float4 *)(b + o.ss0); p.q_shp_sh[1] = (float4 *)(b + o.ss1);
-    p.q_sray_occ = (uint32_t *)(b + o.occ);
-    p.q_ext_ray[0] = (float4 *)(b + o.qr0); p.q_ext_ray[1] = (float4 *)(b + o.qr1);
-    p.q_ext_arg[0] = (float4 *)(b + o.qa0); p.q_ext_arg[1] = (float4 *)(b + o.qa1);
-    p.q_ext_hit = (float4 *)(b + o.qh);
-    p.q_shpath[0] = (float4 *)(b + o.qs0); p.q_shpath[1] = (float4 *)(b + o.qs1);
-    p.q_sray_a = (float4 *)(b + o.ra); p.q_sray_b = (float4 *)(b + o.rb);
-    p.q_free = (uint32_t *)(b + o.free_); p.qcnt = (unsigned long long *)(b + o.cnt);
-    p.it = (IterArgs *)(b + o.it);
-    rs->pool = p;
-    rs->pool_cap = cap; rs->pool_bounces = bounces; rs->pool_nlights = (int)rs->nlights;
+    for (int l = 0; l < lanes; ++l) {
+        const Off &o = of[l];
+        Pool p{};
+        p.cap = cap; p.nframes = nframes; p.nshadow = nshadow; p.ntrk = ntrk;
+        p.fr = (float4 *)(b + o.fr); p.trk = (float *)(b + o.trk);
+        p.q_ext_sh[0] = (float4 *)(b + o.xs0); p.q_ext_sh[1] = (float4 *)(b + o.xs1);
+        p.q_shp_sh[0] = (float4 *)(b + o.ss0); p.q_shp_sh[1] = (float4 *)(b + o.ss1);
+        p.q_sray_occ = (uint32_t *)(b + o.occ);
+        p.q_ext_ray[0] = (float4 *)(b + o.qr0); p.q_ext_ray[1] = (float4 *)(b + o.qr1);
+        p.q_ext_arg[0] = (float4 *)(b + o.qa0); p.q_ext_arg[1] = (float4 *)(b + o.qa1);
+        p.q_ext_hit = (float4 *)(b + o.qh);
+        p.q_shpath[0] = (float4 *)(b + o.qs0); p.q_shpath[1] = (float4 *)(b + o.qs1);
+        p.q_sray_a = (float4 *)(b + o.ra); p.q_sray_b = (float4 *)(b + o.rb);
+        p.q_free = (uint32_t *)(b + o.free_); p.qcnt = (unsigned long long *)(b + o.cnt);
+        p.it = (IterArgs *)(b + o.it);
+        rs->pools[l] = p;
+    }
+    rs->pool_cap = cap; rs->pool_bounces = bounces; rs->pool_nlights = (int)rs->nlights; rs->pool_lanes = lanes;
     return PTMI_OK;
 }
 
@@ -1225,10 +1252,11 @@ constexpr uint32_t VOTE_NEVER = 0xFFFFFFFFu;
 // One iteration of the wavefront loop on queue buffer `cur`, enqueued without knowing its sizes (IterArgs); the grids
 // cover the most paths the call can have in flight (the pool, or all of the call's samples if those are fewer).
 template <int STACK>
-static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, int cur, hipStream_t s) {
-    const uint64_t most = std::min<uint64_t>(pl.cap, ra.total);
+static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, uint64_t lane_total, int cur,
+                               hipStream_t s) {
+    const uint64_t most = std::min<uint64_t>(pl.cap, lane_total);
     const unsigned cap_wgs = (unsigned)((most + 255) / 256), cap_waves = (unsigned)((most + WAVE - 1) / WAVE);
-    hipLaunchKernelGGL(iter_prep_kernel, dim3(1), dim3(64), 0, s, pl, cur, (unsigned long long)ra.total, ctx->d_counters);
+    hipLaunchKernelGGL(iter_prep_kernel, dim3(1), dim3(64), 0, s, pl, cur, (unsigned long long)lane_total, ctx->d_counters);
     hipLaunchKernelGGL(generate_kernel, dim3(cap_wgs), dim3(256), 0, s, pl, ra, cur);
     // extend
     uint32_t vote_from = VOTE_NEVER;
@@ -1268,13 +1296,14 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
     PTMI_HIP(ctx, hipGetLastError());
     return PTMI_OK;
 }
-static int enqueue_iteration(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, int cur, hipStream_t s) {
+static int enqueue_iteration(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, uint64_t lane_total, int cur,
+                             hipStream_t s) {
     const int dep = ctx->max_depth;      // the LDS stack is as deep as the tree
-    if (dep <= 16) return enqueue_iteration_t<16>(ctx, pl, sc, ra, cur, s);
-    if (dep <= 24) return enqueue_iteration_t<24>(ctx, pl, sc, ra, cur, s);
-    if (dep <= 32) return enqueue_iteration_t<32>(ctx, pl, sc, ra, cur, s);
-    if (dep <= 48) return enqueue_iteration_t<48>(ctx, pl, sc, ra, cur, s);
-    return enqueue_iteration_t<64>(ctx, pl, sc, ra, cur, s);
+    if (dep <= 16) return enqueue_iteration_t<16>(ctx, pl, sc, ra, lane_total, cur, s);
+    if (dep <= 24) return enqueue_iteration_t<24>(ctx, pl, sc, ra, lane_total, cur, s);
+    if (dep <= 32) return enqueue_iteration_t<32>(ctx, pl, sc, ra, lane_total, cur, s);
+    if (dep <= 48) return enqueue_iteration_t<48>(ctx, pl, sc, ra, lane_total, cur, s);
+    return enqueue_iteration_t<64>(ctx, pl, sc, ra, lane_total, cur, s);
 }
 
 // Renders samples [spp_begin, spp_begin+spp_count) of the rectangle into d_out chunks and accumulates them
@@ -1316,7 +1345,16 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     const uint64_t path_bytes = pool_bytes_per_path(bounces, (int)rs->nlights);
     const uint64_t by_targets = 0xFFFFFFFFull / ((uint64_t)(bounces + 1) * (rs->nlights + 2));   // shadow-ray queue positions are 32-bit
     const uint64_t by_budget = std::min(by_targets, std::max<uint64_t>(1u << 16, ctx->pool_bytes_max / path_bytes));
-    uint32_t cap = (uint32_t)std::min<uint64_t>({max_total, (uint64_t)ctx->pool_paths, by_budget});
+    // Two independent loops ("lanes"), each on half of the pool and of the samples and on a stream of its own, when
+    // there is work for both: shade waits on memory most of the time while extend and connect keep the VALUs busy, so
+    // one lane's traversal kernels fill the tails of the other's shade (shade's LDS leaves no room for more overlap
+    // than that).  Measured: +3 % on C3, +8 % on C1, +1 % on the black-hole march, nothing with an 88 MB tree, -2 % with
+    // a 672 MB tree (two kernels' working sets in the caches instead of one), so by default (render_lanes < 0) two
+    // lanes run when the packed tree fits the L2s (8 x 4 MB).  The image does not depend on the split.
+    const uint64_t tree_bytes = ctx->packed_inner * 64 + ctx->packed_tris * 48;
+    const int want_lanes = ctx->render_lanes < 0 ? (tree_bytes <= (32ull << 20) ? 2 : 1) : ctx->render_lanes;
+    const int lanes = (want_lanes >= 2 && max_total >= (1ull << 22)) ? 2 : 1;
+    uint32_t cap = (uint32_t)std::min<uint64_t>({(max_total + lanes - 1) / lanes, (uint64_t)ctx->pool_paths / lanes, by_budget / lanes});
     cap = (cap + 255) / 256 * 256;
     // the per-sample output buffer first (its size is fixed by the request), then as large a pool as fits
     if (rs->out_bytes < max_total * 12) {
@@ -1325,18 +1363,20 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         rs->out_bytes = max_total * 12;
     }
     int rc;
-    while ((rc = ensure_pool(ctx, cap, bounces)) == PTMI_ERR_OOM && cap > (1u << 16))
+    while ((rc = ensure_pool(ctx, cap, bounces, lanes)) == PTMI_ERR_OOM && cap > (1u << 16))
         cap = (cap / 2 + 255) / 256 * 256;          // device memory is short (other contexts on this GPU): halve
     if (rc == PTMI_ERR_OOM) return set_err(ctx, PTMI_ERR_OOM, "ptmi_render: out of device memory for the path pool");
     if (rc) return rc;
     if (!rs->h_qc) {
-        for (hipEvent_t &e : rs->ev_qc) PTMI_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        PTMI_HIP(ctx, hipHostMalloc((void **)&rs->h_qc, RenderState::QC_RING * QC_COUNT * QC_STRIDE * sizeof(unsigned long long), hipHostMallocDefault));
+        for (auto &lane : rs->ev_qc) for (hipEvent_t &e : lane) PTMI_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        PTMI_HIP(ctx, hipEventCreateWithFlags(&rs->ev_fork, hipEventDisableTiming));
+        PTMI_HIP(ctx, hipEventCreateWithFlags(&rs->ev_join, hipEventDisableTiming));
+        PTMI_HIP(ctx, hipStreamCreateWithFlags(&rs->lane_stream, hipStreamNonBlocking));
+        PTMI_HIP(ctx, hipHostMalloc((void **)&rs->h_qc, RenderState::MAX_LANES * RenderState::QC_RING * QC_COUNT * QC_STRIDE * sizeof(unsigned long long),
+                                    hipHostMallocDefault));
     }
-    Pool pl = rs->pool;          // a larger pool than asked for may be in place: its queues are laid out for ITS capacity
-    pl.out = rs->d_out;
     {
-        const size_t ray_lds = (size_t)(SRW * pl.nshadow - 1) * 256 * sizeof(float);
+        const size_t ray_lds = (size_t)(SRW * rs->pools[0].nshadow - 1) * 256 * sizeof(float);
         if (ray_lds > (28u << 10))      // beyond the default 64 KB of LDS per workgroup (gfx950 has 160 KB)
             PTMI_HIP(ctx, hipFuncSetAttribute((const void *)shade_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds));
     }
@@ -1361,33 +1401,65 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         // it has enqueued, so the GPU never waits for the host.  The batches enqueued after the pool drained are empty
         // iterations (every kernel leaves at once): at most 2 * iters_per_batch of them.
         const size_t qc_words = (size_t)QC_COUNT * QC_STRIDE;
-        const uint32_t n0 = (uint32_t)std::min<uint64_t>(pl.cap, ra.total);
-        hipLaunchKernelGGL(iter_init_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, pl, n0);
-        PTMI_HIP(ctx, hipGetLastError());
-        int cur = 0;
         const int iters_per_batch = std::max(1, ctx->render_batch_iters);
-        auto enqueue_batch = [&](int slot) -> int {
+        struct Lane {
+            Pool pl; RenderArgs ra; hipStream_t st; uint64_t total; int cur = 0; bool active = true;
+            unsigned long long *hc; hipEvent_t *ev;
+        } L[RenderState::MAX_LANES];
+        ra.nlanes = (uint32_t)lanes;
+        if (lanes > 1) {            // lane 1's stream joins the caller's stream here and hands back at the end of the pass
+            PTMI_HIP(ctx, hipEventRecord(rs->ev_fork, s));
+            PTMI_HIP(ctx, hipStreamWaitEvent(rs->lane_stream, rs->ev_fork, 0));
+        }
+        for (int l = 0; l < lanes; ++l) {
+            Lane &ln = L[l];
+            ln.pl = rs->pools[l];   // a larger pool than asked for may be in place: its queues are laid out for ITS capacity
+            ln.pl.out = rs->d_out;
+            ln.ra = ra; ln.ra.lane = (uint32_t)l;
+            ln.st = l == 0 ? s : rs->lane_stream;
+            ln.total = lane_sample_count(ra.total, (uint32_t)l, (uint32_t)lanes);
+            ln.hc = rs->h_qc + (size_t)l * RenderState::QC_RING * qc_words;
+            ln.ev = rs->ev_qc[l];
+            ln.active = ln.total > 0;
+            if (!ln.active) continue;
+            const uint32_t n0 = (uint32_t)std::min<uint64_t>(ln.pl.cap, ln.total);
+            hipLaunchKernelGGL(iter_init_kernel, dim3((n0 + 255) / 256), dim3(256), 0, ln.st, ln.pl, n0);
+            PTMI_HIP(ctx, hipGetLastError());
+        }
+        auto enqueue_batch = [&](Lane &ln, int slot) -> int {
             for (int k = 0; k < iters_per_batch; ++k) {
-                int r = enqueue_iteration(ctx, pl, sc, ra, cur, s);
+                int r = enqueue_iteration(ctx, ln.pl, sc, ln.ra, ln.total, ln.cur, ln.st);
                 if (r) return r;
-                cur ^= 1;
+                ln.cur ^= 1;
             }
             // the counters as the batch's last shade left them: queue lengths of buffer `cur`, samples handed out
-            PTMI_HIP(ctx, hipMemcpyAsync(rs->h_qc + (size_t)slot * qc_words, pl.qcnt, qc_words * sizeof(unsigned long long),
-                                         hipMemcpyDeviceToHost, s));
-            PTMI_HIP(ctx, hipEventRecord(rs->ev_qc[slot], s));
+            PTMI_HIP(ctx, hipMemcpyAsync(ln.hc + (size_t)slot * qc_words, ln.pl.qcnt, qc_words * sizeof(unsigned long long),
+                                         hipMemcpyDeviceToHost, ln.st));
+            PTMI_HIP(ctx, hipEventRecord(ln.ev[slot], ln.st));
             return PTMI_OK;
         };
-        if ((rc = enqueue_batch(0))) return rc;
-        for (uint64_t batch = 0;; ++batch) {
+        for (int l = 0; l < lanes; ++l)
+            if (L[l].active && (rc = enqueue_batch(L[l], 0))) return rc;
+        for (uint64_t batch = 0; L[0].active || (lanes > 1 && L[1].active); ++batch) {
             if (batch > 100000000ull) return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: wavefront loop did not terminate");
             const int slot = (int)(batch % RenderState::QC_RING), ahead = (int)((batch + 1) % RenderState::QC_RING);
-            const int cur_then = cur;                       // the buffer batch `batch` left its queues in
-            if ((rc = enqueue_batch(ahead))) return rc;
-            PTMI_HIP(ctx, hipEventSynchronize(rs->ev_qc[slot]));
-            const unsigned long long *hc = rs->h_qc + (size_t)slot * qc_words;
-            const unsigned long long left = hc[(QC_EXT0 + cur_then) * QC_STRIDE] + hc[(QC_SHP0 + cur_then) * QC_STRIDE];
-            if (left == 0 && hc[QC_NEXT * QC_STRIDE] >= ra.total) break;
+            int cur_then[RenderState::MAX_LANES];           // the buffer batch `batch` left each lane's queues in
+            for (int l = 0; l < lanes; ++l) {
+                cur_then[l] = L[l].cur;
+                if (L[l].active && (rc = enqueue_batch(L[l], ahead))) return rc;
+            }
+            for (int l = 0; l < lanes; ++l) {
+                Lane &ln = L[l];
+                if (!ln.active) continue;
+                PTMI_HIP(ctx, hipEventSynchronize(ln.ev[slot]));
+                const unsigned long long *hc = ln.hc + (size_t)slot * qc_words;
+                const unsigned long long left = hc[(QC_EXT0 + cur_then[l]) * QC_STRIDE] + hc[(QC_SHP0 + cur_then[l]) * QC_STRIDE];
+                if (left == 0 && hc[QC_NEXT * QC_STRIDE] >= ln.total) ln.active = false;
+            }
+        }
+        if (lanes > 1) {
+            PTMI_HIP(ctx, hipEventRecord(rs->ev_join, rs->lane_stream));
+            PTMI_HIP(ctx, hipStreamWaitEvent(s, rs->ev_join, 0));
         }
         {   // integrator self-checks (ERR_*): any bit set means a path record was corrupt
             unsigned long long hcnt[CNT_WORDS];

@@ -304,7 +304,8 @@ def test_traversal_kernel_forms_agree_bit_for_bit(monkeypatch):
     persistent kernel for long queues and one-shot waves for short ones (PTMI_CONNECT_VOTE=0 / PTMI_EXTEND_VOTE=0 switch
     the vote-scheduled form off, PTMI_RENDER_VOTE_MIN moves the bound).  The answer of a walk is a pure function of the
     ray, so all of them give the same sums bit for bit -- and so does any number of iterations enqueued between two
-    looks at the queue counters (PTMI_RENDER_BATCH_ITERS).
+    looks at the queue counters (PTMI_RENDER_BATCH_ITERS) (the split of the samples over two wavefront
+    loops needs 4 M samples: test_two_lanes_equal_one).
     (test_many_lights runs the shared last bucket through the default form against the oracle.)"""
     from pathtrace_amd import Context
     sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
@@ -312,10 +313,10 @@ def test_traversal_kernel_forms_agree_bit_for_bit(monkeypatch):
     frames = []
     # launches this small run the one-shot kernels unless PTMI_RENDER_VOTE_MIN=0 forces the vote-scheduled ones;
     # 20000 puts the bound inside this render's range of queue lengths (30 720 samples at the start, a tail at the end)
-    for vote, ext, vmin, batch in ((None, None, "0", None), ("0", "0", "0", None), ("0", "1", "0", "1"), (None, None, "20000", "7"),
-                                   (None, None, None, None), ("1", "0", "0", "2")):
+    for vote, ext, vmin, batch, lanes in ((None, None, "0", None, "1"), ("0", "0", "0", None, "2"), ("0", "1", "0", "1", None),
+                                          (None, None, "20000", "7", "2"), (None, None, None, None, None), ("1", "0", "0", "2", "1")):
         for var, val in (("PTMI_CONNECT_VOTE", vote), ("PTMI_EXTEND_VOTE", ext), ("PTMI_RENDER_VOTE_MIN", vmin),
-                         ("PTMI_RENDER_BATCH_ITERS", batch)):
+                         ("PTMI_RENDER_BATCH_ITERS", batch), ("PTMI_RENDER_LANES", lanes)):
             if val is None:
                 monkeypatch.delenv(var, raising=False)
             else:
@@ -330,6 +331,34 @@ def test_traversal_kernel_forms_agree_bit_for_bit(monkeypatch):
             ctx.close()
     for a, c in frames[1:]:
         assert np.array_equal(a, frames[0][0]) and np.array_equal(c, frames[0][1])
+
+
+def test_two_lanes_equal_one(monkeypatch):
+    """PTMI_RENDER_LANES=2 deals the samples of a pass in blocks of 65 536 to two independent wavefront loops on two
+    streams (each with half of the pool); the sums equal the one-loop render bit for bit.  The two sizes end in a short
+    last block that belongs to lane 0 (67 blocks) and to lane 1 (68 blocks)."""
+    import torch
+    from pathtrace_amd import Context
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    dev = torch.device("cuda", 0)
+    for W, H, spp in ((500, 300, 29), (440, 500, 20)):
+        assert W * H * spp >= 1 << 22
+        p = make_params(W, H, bounces=2, seed=3)
+        frames = []
+        for lanes in ("1", "2"):
+            monkeypatch.setenv("PTMI_RENDER_LANES", lanes)
+            ctx = Context(0)
+            try:
+                r = Renderer(sc, ctx=ctx)
+                a = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+                c = torch.zeros((H, W), dtype=torch.int32, device=dev)
+                r.render_device(a, c, p, sc.camera, spp=spp)
+                r.render_device(a, c, p, sc.camera, spp=3, spp_begin=spp)      # a pass too small for two lanes, same buffers
+                frames.append((a.cpu(), c.cpu()))
+            finally:
+                ctx.close()
+        assert bool((frames[0][1] == spp + 3).all())
+        assert torch.equal(frames[0][0], frames[1][0]) and torch.equal(frames[0][1], frames[1][1])
 
 
 def test_full_size_frame_properties(gpu_ctx):
