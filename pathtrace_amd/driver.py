@@ -114,9 +114,13 @@ class Stats:
                 f"({100.0 * samples / self.total:.1f}%)  {int(el) // 60:02d}:{int(el) % 60:02d} / {rem // 60:02d}:{rem % 60:02d}")
 
 
-def frame_loop(renderer, scene, params, frames=1, spp=32, splits=(4, 4), out_dir=None, orbit=None, log=print):
+def frame_loop(renderer, scene, params, frames=1, spp=32, splits=(4, 4), out_dir=None, orbit=None, log=print,
+               checkpoint=None):
     """main.go:454-491 tiles, :832-899 per-tile work, :904-939 write the frame / orbit / restart.
-    orbit = (radius, theta0, phi): SphericalAround(origin, radius, theta, phi) with theta += 1 degree per frame."""
+    orbit = (radius, theta0, phi): SphericalAround(origin, radius, theta, phi) with theta += 1 degree per frame.
+    checkpoint = a path: the first frame's sums and counts are written there after every tile, and a file found there
+    at the start is continued (tiles that already have their samples are skipped); the reference has no such thing."""
+    from .render import Framebuffer
     W, H = params.width, params.height
     sx, sy = splits
     tw, th = W // sx, H // sy
@@ -125,13 +129,23 @@ def frame_loop(renderer, scene, params, frames=1, spp=32, splits=(4, 4), out_dir
     images = []
     for j in range(1, frames + 1):
         fb = renderer.new_framebuffer(W, H)
+        if checkpoint and j == 1 and os.path.exists(checkpoint):
+            old = Framebuffer.load(checkpoint)
+            if old.counts.shape == (H, W):
+                fb = old
+                log(f">> resuming {checkpoint}: {int(fb.counts.sum())} of {W * H * spp} samples done")
         stats = Stats(W * H * spp)
         renderer.bvh.reset_counters()
         for i in range(sx * sy):                               # tile i covers block (i % splitsX, i / splitsX)
             x0, y0 = (i % sx) * tw, (i // sx) * th
-            renderer.render_tile(fb, params, cam, (x0, y0, tw, th), spp=spp)
+            have = int(fb.counts[y0:y0 + th, x0:x0 + tw].min())           # a tile is sampled uniformly (one call)
+            if have >= spp:
+                continue
+            renderer.render_tile(fb, params, cam, (x0, y0, tw, th), spp=spp - have, spp_begin=have)
             c = renderer.bvh.counters()
             log(stats.update(int(c.diffuse_events), int(c.samples)))
+            if checkpoint and j == 1:
+                fb.save(checkpoint)
         rgba = renderer.to_rgba(fb)
         images.append(rgba)
         if out_dir:
@@ -154,6 +168,7 @@ def main():
     ap.add_argument("--spp", type=int, default=32); ap.add_argument("--bounces", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1); ap.add_argument("--out", default="orbit")
     ap.add_argument("--orbit-radius", type=float, default=0.0)
+    ap.add_argument("--checkpoint", default=None, help="save the first frame's sums/counts here after every tile; continue a file found there")
     a = ap.parse_args()
     if a.obj:
         from .obj import LoadObj
@@ -173,7 +188,7 @@ def main():
     orbit = None
     if a.orbit_radius > 0 or a.scene == "c5":
         orbit = (a.orbit_radius or 1500.0, 90.0 * DEG, 83.0 * DEG)      # main.go:625-631
-    frame_loop(r, sc, p, frames=a.frames, spp=a.spp, out_dir=a.out, orbit=orbit)
+    frame_loop(r, sc, p, frames=a.frames, spp=a.spp, out_dir=a.out, orbit=orbit, checkpoint=a.checkpoint)
 
 
 if __name__ == "__main__":

@@ -47,6 +47,27 @@ class Framebuffer:
     def mean(self):
         return self.accum / np.maximum(self.counts, 1)[..., None].astype(np.float32)
 
+    # Checkpoint / resume.  The reference has none (its only outputs are PNGs, main.go:770-778, :916-924); the sums and
+    # counts ARE the whole state of a frame in progress, and because a sample's RNG stream is keyed by (pixel, sample
+    # number), rendering samples [n, m) into a reloaded framebuffer gives the same sums as never having stopped.
+    def save(self, path):
+        """Write the accumulation state (f32 sums, u32 counts) as an .npz file."""
+        with open(path, "wb") as f:
+            np.savez(f, accum=self.accum, counts=self.counts)
+
+    @staticmethod
+    def load(path) -> "Framebuffer":
+        with np.load(path, allow_pickle=False) as z:
+            accum, counts = np.ascontiguousarray(z["accum"], np.float32), np.ascontiguousarray(z["counts"], np.uint32)
+        if accum.ndim != 3 or accum.shape[2] != 3 or counts.shape != accum.shape[:2]:
+            raise ValueError(f"{path}: not a framebuffer checkpoint (accum {accum.shape}, counts {counts.shape})")
+        return Framebuffer(accum, counts)
+
+    @property
+    def samples_done(self) -> int:
+        """Samples every pixel has (the next sample number to render when resuming a uniformly sampled frame)."""
+        return int(self.counts.min()) if self.counts.size else 0
+
 
 class Renderer:
     def __init__(self, sc: SceneData, device=0, ctx: Context | None = None, threshold=4, depth=42):

@@ -42,3 +42,20 @@ def test_png_round_trip(tmp_path):
     got = read_image(tmp_path / "f.png")
     want = rgba[..., 0].astype(np.uint32) | (rgba[..., 1].astype(np.uint32) << 8) | (rgba[..., 2].astype(np.uint32) << 16) | (rgba[..., 3].astype(np.uint32) << 24)
     assert np.array_equal(got, want)
+
+
+def test_framebuffer_checkpoint_round_trip(tmp_path):
+    """The accumulation state of a frame in progress survives save / load bit for bit; a file of another shape is refused."""
+    import pytest
+    from pathtrace_amd.render import Framebuffer
+    rng = np.random.default_rng(1)
+    fb = Framebuffer(rng.random((5, 7, 3), dtype=np.float32) * 9, np.full((5, 7), 12, np.uint32))
+    fb.counts[2, 3] = 11
+    fb.save(tmp_path / "fb.npz")
+    got = Framebuffer.load(tmp_path / "fb.npz")
+    assert got.accum.dtype == np.float32 and got.counts.dtype == np.uint32
+    assert np.array_equal(got.accum.view(np.uint32), fb.accum.view(np.uint32)) and np.array_equal(got.counts, fb.counts)
+    assert got.samples_done == 11
+    np.savez(tmp_path / "bad.npz", accum=np.zeros((5, 7), np.float32), counts=np.zeros((5, 7), np.uint32))
+    with pytest.raises(ValueError):
+        Framebuffer.load(tmp_path / "bad.npz")

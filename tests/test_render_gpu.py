@@ -333,6 +333,36 @@ def test_traversal_kernel_forms_agree_bit_for_bit(monkeypatch):
         assert np.array_equal(a, frames[0][0]) and np.array_equal(c, frames[0][1])
 
 
+def test_checkpoint_and_resume(gpu_ctx, tmp_path):
+    """A frame stopped after 6 of 10 samples, written to disk, reloaded and continued equals the frame rendered in one
+    go bit for bit (checkpoint / resume, which the reference does not have)."""
+    from pathtrace_amd.render import Framebuffer
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    p = make_params(64, 48, bounces=2, seed=4)
+    r = Renderer(sc, ctx=gpu_ctx)
+    whole = r.new_framebuffer(64, 48)
+    r.render_tile(whole, p, sc.camera, spp=10)
+    part = r.new_framebuffer(64, 48)
+    r.render_tile(part, p, sc.camera, spp=6)
+    part.save(tmp_path / "frame.npz")
+    resumed = Framebuffer.load(tmp_path / "frame.npz")
+    assert resumed.samples_done == 6
+    r.render_tile(resumed, p, sc.camera, spp=10 - resumed.samples_done, spp_begin=resumed.samples_done)
+    assert np.array_equal(resumed.accum.view(np.uint32), whole.accum.view(np.uint32)) and np.array_equal(resumed.counts, whole.counts)
+    # the frame loop: a checkpoint with 5 of 16 tiles done (3 of them only half sampled) is continued, not restarted
+    from pathtrace_amd import driver
+    want = driver.frame_loop(r, sc, p, frames=1, spp=4, log=lambda _l: None)[0]
+    started = r.new_framebuffer(64, 48)
+    for i in range(5):
+        r.render_tile(started, p, sc.camera, ((i % 4) * 16, (i // 4) * 12, 16, 12), spp=4 if i < 2 else 2)
+    started.save(tmp_path / "loop.npz")
+    lines = []
+    got = driver.frame_loop(r, sc, p, frames=1, spp=4, log=lines.append, checkpoint=str(tmp_path / "loop.npz"))[0]
+    assert np.array_equal(got, want)
+    assert sum("rays/s" in l for l in lines) == 14 and any("resuming" in l for l in lines)
+    assert Framebuffer.load(tmp_path / "loop.npz").samples_done == 4
+
+
 def test_two_lanes_equal_one(monkeypatch):
     """PTMI_RENDER_LANES=2 deals the samples of a pass in blocks of 65 536 to two independent wavefront loops on two
     streams (each with half of the pool); the sums equal the one-loop render bit for bit.  The two sizes end in a short
