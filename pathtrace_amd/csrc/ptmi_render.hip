@@ -1236,15 +1236,16 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
 }
 
 // A persistent wave of the vote-scheduled kernels reserves three chunks of queue entries before it starts (one in use,
-// two ahead), so a launch needs at least 3 * 64 rays per resident wave for every wave to get work at all, and measured
-// (tools/ab_env_tiles.sh) the one-shot kernels stay ahead up to about eight times that: 10 M rays on this chip.  Below
-// the bound the one-shot kernels run (the draining iterations at the end of a call, tiles rendered one per call),
+// two ahead), so a launch needs at least 3 * 64 rays per resident wave for every wave to get work at all; measured
+// (PTMI_RENDER_VOTE_MIN sweeps on C1, C3 and the 10 M-triangle scene, profiles/r02c) the vote-scheduled kernels are
+// ahead from about four times that, 5 M rays on this chip (round 1, with scattered answer stores: eight times).  Below the
+// bound the one-shot kernels run (the draining iterations at the end of a call, small tiles rendered one per call),
 // above it the vote-scheduled ones with chunks of up to render_vote_chunk entries.  Both kernels are enqueued every
 // iteration and the one the queue length does not belong to leaves at once (the length is only known on the device).
 // PTMI_RENDER_VOTE_MIN overrides the bound (tests force the vote-scheduled kernels at small sizes with 0).
 static uint32_t vote_from_for(const ptmi_ctx *ctx, int per_cu) {
     const uint64_t waves = (uint64_t)ctx->num_cus * (uint64_t)per_cu;
-    const uint64_t least = ctx->render_vote_min >= 0 ? (uint64_t)ctx->render_vote_min : waves * 3 * WAVE * 8;
+    const uint64_t least = ctx->render_vote_min >= 0 ? (uint64_t)ctx->render_vote_min : waves * 3 * WAVE * 4;
     return (uint32_t)std::min<uint64_t>(least, 0xFFFFFFFEull);
 }
 constexpr uint32_t VOTE_NEVER = 0xFFFFFFFFu;

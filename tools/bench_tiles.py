@@ -17,7 +17,8 @@ dev = torch.device("cuda", 0)
 acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev); cnt = torch.zeros((H, W), dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 rr = sharded.make_device_render_rect(r, p, sc.camera, st)
-rr(acc, cnt, (0, 0, W, H), 0, 1); torch.cuda.synchronize()
+rr(acc, cnt, (0, 0, W, H), 0, spp); torch.cuda.synchronize()   # warm-up at full size: pool and sample buffer allocation
+rr(acc, cnt, (8, 8, 16, 16), 0, 1); torch.cuda.synchronize()    # ... and torch's strided add of a sub-rectangle (its first use loads a code object: ~55 ms)
 split = [(x, y, 480, 270) for y in range(0, H, 270) for x in range(0, W, 480)]
 small = sharded.tile_rects(W, H, 64)
 for name, calls in (("whole frame, one call", [[(0, 0, W, H)]]), ("4x4 split, one call per tile", [[t] for t in split]),
@@ -32,6 +33,7 @@ for name, calls in (("whole frame, one call", [[(0, 0, W, H)]]), ("4x4 split, on
         per_call.append(time.time() - t1)           # the render calls return when the region is done
     torch.cuda.synchronize(); dt = time.time() - t0
     assert bool((cnt == spp).all())
+    if 1 < len(per_call) <= 16: print("   per call, in order (ms):", " ".join(f"{t * 1e3:.1f}" for t in per_call))
     per_call.sort()
     print(f"{name}: {len(calls)} calls, {W * H * spp / dt / 1e6:.1f} Msamples/s; per call min / median / max "
           f"{per_call[0] * 1e3:.2f} / {per_call[len(per_call) // 2] * 1e3:.2f} / {per_call[-1] * 1e3:.2f} ms")
