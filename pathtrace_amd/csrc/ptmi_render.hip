@@ -1265,8 +1265,9 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
         const int per_cu = std::min(ctx->waves_per_cu((const void *)render_extend_vote_kernel<STACK>, WAVE), ctx->persist_waves_per_cu);
         vote_from = vote_from_for(ctx, per_cu);
         const unsigned pgrid = (unsigned)std::min<uint64_t>(cap_waves, (uint64_t)ctx->num_cus * per_cu);
-        hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, cur, vote_from,
-                           ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk);
+        if (most >= vote_from)          // a call this small never has a queue that long: one launch less per iteration
+            hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, cur, vote_from,
+                               ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk);
     }
     if (vote_from > 0) {
         const unsigned grid = (unsigned)std::min<uint64_t>(cap_waves, ((uint64_t)vote_from + WAVE - 1) / WAVE);
@@ -1284,8 +1285,9 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
         const int per_cu = std::min(ctx->waves_per_cu((const void *)render_connect_vote_kernel<STACK>, WAVE), ctx->persist_waves_per_cu);
         vote_from = vote_from_for(ctx, per_cu);
         const unsigned pgrid = (unsigned)std::min<uint64_t>(ray_waves, (uint64_t)ctx->num_cus * per_cu);
-        hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, vote_from,
-                           ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk);
+        if (most * (uint64_t)pl.nshadow >= vote_from)
+            hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, vote_from,
+                               ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk);
     }
     if (vote_from > 0) {
         const unsigned grid = (unsigned)std::min<uint64_t>(ray_waves, ((uint64_t)vote_from + WAVE - 1) / WAVE);
