@@ -1030,13 +1030,13 @@ struct RenderState {
     // pool (device), sized for (cap, bounces, nlights)
     char *pool_mem = nullptr; size_t pool_bytes = 0;
     uint32_t pool_cap = 0; int pool_bounces = -2, pool_nlights = -1, pool_lanes = 0;
-    enum { MAX_LANES = 2, QC_RING = 2 };
+    enum { MAX_LANES = 4, QC_RING = 2 };
     Pool pools[MAX_LANES]{};             // one per lane (render_core)
-    hipStream_t lane_stream = nullptr;   // lane 1 runs here, lane 0 on the caller's stream
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t lane_stream[MAX_LANES] = {};   // lanes 1 .. run here, lane 0 on the caller's stream
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {};
     // the host's view of the queue counters: per lane one pinned copy per batch of iterations in flight (render_core)
     unsigned long long *h_qc = nullptr;  // pinned, MAX_LANES x QC_RING x QC_COUNT * QC_STRIDE words
-    hipEvent_t ev_qc[MAX_LANES][QC_RING] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipEvent_t ev_qc[MAX_LANES][QC_RING] = {};
     float *d_out = nullptr; size_t out_bytes = 0;
     char *d_tiles = nullptr; size_t tiles_bytes = 0;   // tile list of ptmi_render_tiles_dev
     float *d_accum = nullptr; uint32_t *d_counts = nullptr; size_t accum_pix = 0;
@@ -1059,8 +1059,9 @@ void free_scene(ptmi_ctx *ctx) {
                     rs->d_sky_img, rs->pool_mem, rs->d_out, rs->d_accum, rs->d_counts, rs->d_tiles};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &lane : rs->ev_qc) for (hipEvent_t e : lane) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {rs->ev_fork, rs->ev_join}) if (e) (void)hipEventDestroy(e);
-    if (rs->lane_stream) (void)hipStreamDestroy(rs->lane_stream);
+    if (rs->ev_fork) (void)hipEventDestroy(rs->ev_fork);
+    for (hipEvent_t e : rs->ev_join) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : rs->lane_stream) if (st) (void)hipStreamDestroy(st);
     if (rs->h_qc) (void)hipHostFree(rs->h_qc);
     delete rs;
     ctx->render = nullptr;
@@ -1353,10 +1354,11 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     // one lane's traversal kernels fill the tails of the other's shade (shade's LDS leaves no room for more overlap
     // than that).  Measured: +3 % on C3, +8 % on C1, +1 % on the black-hole march, nothing with an 88 MB tree, -2 % with
     // a 672 MB tree (two kernels' working sets in the caches instead of one), so by default (render_lanes < 0) two
-    // lanes run when the packed tree fits the L2s (8 x 4 MB).  The image does not depend on the split.
+    // lanes run when the packed tree fits the L2s (8 x 4 MB); three lanes are 4 % slower than two on C3, four 9 % (each
+    // lane's queues get shorter).  The image does not depend on the split.
     const uint64_t tree_bytes = ctx->packed_inner * 64 + ctx->packed_tris * 48;
     const int want_lanes = ctx->render_lanes < 0 ? (tree_bytes <= (32ull << 20) ? 2 : 1) : ctx->render_lanes;
-    const int lanes = (want_lanes >= 2 && max_total >= (1ull << 22)) ? 2 : 1;
+    const int lanes = (want_lanes >= 2 && max_total >= (1ull << 22)) ? std::min(want_lanes, (int)RenderState::MAX_LANES) : 1;
     uint32_t cap = (uint32_t)std::min<uint64_t>({(max_total + lanes - 1) / lanes, (uint64_t)ctx->pool_paths / lanes, by_budget / lanes});
     cap = (cap + 255) / 256 * 256;
     // the per-sample output buffer first (its size is fixed by the request), then as large a pool as fits
@@ -1373,8 +1375,10 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     if (!rs->h_qc) {
         for (auto &lane : rs->ev_qc) for (hipEvent_t &e : lane) PTMI_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         PTMI_HIP(ctx, hipEventCreateWithFlags(&rs->ev_fork, hipEventDisableTiming));
-        PTMI_HIP(ctx, hipEventCreateWithFlags(&rs->ev_join, hipEventDisableTiming));
-        PTMI_HIP(ctx, hipStreamCreateWithFlags(&rs->lane_stream, hipStreamNonBlocking));
+        for (int l = 1; l < RenderState::MAX_LANES; ++l) {
+            PTMI_HIP(ctx, hipEventCreateWithFlags(&rs->ev_join[l], hipEventDisableTiming));
+            PTMI_HIP(ctx, hipStreamCreateWithFlags(&rs->lane_stream[l], hipStreamNonBlocking));
+        }
         PTMI_HIP(ctx, hipHostMalloc((void **)&rs->h_qc, RenderState::MAX_LANES * RenderState::QC_RING * QC_COUNT * QC_STRIDE * sizeof(unsigned long long),
                                     hipHostMallocDefault));
     }
@@ -1410,16 +1414,16 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             unsigned long long *hc; hipEvent_t *ev;
         } L[RenderState::MAX_LANES];
         ra.nlanes = (uint32_t)lanes;
-        if (lanes > 1) {            // lane 1's stream joins the caller's stream here and hands back at the end of the pass
+        if (lanes > 1) {            // the other lanes' streams join the caller's stream here and hand back at the end of the pass
             PTMI_HIP(ctx, hipEventRecord(rs->ev_fork, s));
-            PTMI_HIP(ctx, hipStreamWaitEvent(rs->lane_stream, rs->ev_fork, 0));
+            for (int l = 1; l < lanes; ++l) PTMI_HIP(ctx, hipStreamWaitEvent(rs->lane_stream[l], rs->ev_fork, 0));
         }
         for (int l = 0; l < lanes; ++l) {
             Lane &ln = L[l];
             ln.pl = rs->pools[l];   // a larger pool than asked for may be in place: its queues are laid out for ITS capacity
             ln.pl.out = rs->d_out;
             ln.ra = ra; ln.ra.lane = (uint32_t)l;
-            ln.st = l == 0 ? s : rs->lane_stream;
+            ln.st = l == 0 ? s : rs->lane_stream[l];
             ln.total = lane_sample_count(ra.total, (uint32_t)l, (uint32_t)lanes);
             ln.hc = rs->h_qc + (size_t)l * RenderState::QC_RING * qc_words;
             ln.ev = rs->ev_qc[l];
@@ -1443,7 +1447,8 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         };
         for (int l = 0; l < lanes; ++l)
             if (L[l].active && (rc = enqueue_batch(L[l], 0))) return rc;
-        for (uint64_t batch = 0; L[0].active || (lanes > 1 && L[1].active); ++batch) {
+        auto any_active = [&]() { for (int l = 0; l < lanes; ++l) if (L[l].active) return true; return false; };
+        for (uint64_t batch = 0; any_active(); ++batch) {
             if (batch > 100000000ull) return set_err(ctx, PTMI_ERR_HIP, "ptmi_render: wavefront loop did not terminate");
             const int slot = (int)(batch % RenderState::QC_RING), ahead = (int)((batch + 1) % RenderState::QC_RING);
             int cur_then[RenderState::MAX_LANES];           // the buffer batch `batch` left each lane's queues in
@@ -1460,9 +1465,9 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
                 if (left == 0 && hc[QC_NEXT * QC_STRIDE] >= ln.total) ln.active = false;
             }
         }
-        if (lanes > 1) {
-            PTMI_HIP(ctx, hipEventRecord(rs->ev_join, rs->lane_stream));
-            PTMI_HIP(ctx, hipStreamWaitEvent(s, rs->ev_join, 0));
+        for (int l = 1; l < lanes; ++l) {
+            PTMI_HIP(ctx, hipEventRecord(rs->ev_join[l], rs->lane_stream[l]));
+            PTMI_HIP(ctx, hipStreamWaitEvent(s, rs->ev_join[l], 0));
         }
         {   // integrator self-checks (ERR_*): any bit set means a path record was corrupt
             unsigned long long hcnt[CNT_WORDS];
