@@ -364,9 +364,9 @@ def test_checkpoint_and_resume(gpu_ctx, tmp_path):
 
 
 def test_two_lanes_equal_one(monkeypatch):
-    """PTMI_RENDER_LANES=2 deals the samples of a pass in blocks of 65 536 to two independent wavefront loops on two
-    streams (each with half of the pool); the sums equal the one-loop render bit for bit.  The two sizes end in a short
-    last block that belongs to lane 0 (67 blocks) and to lane 1 (68 blocks)."""
+    """PTMI_RENDER_LANES=n deals the samples of a pass in blocks of 65 536 to n independent wavefront loops on n
+    streams (each with its share of the pool); the sums equal the one-loop render bit for bit.  The two sizes end in a
+    short last block that belongs to lane 0 (67 blocks; of three lanes too) and to lane 1 (68 blocks)."""
     import torch
     from pathtrace_amd import Context
     sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
@@ -375,7 +375,7 @@ def test_two_lanes_equal_one(monkeypatch):
         assert W * H * spp >= 1 << 22
         p = make_params(W, H, bounces=2, seed=3)
         frames = []
-        for lanes in ("1", "2"):
+        for lanes in ("1", "2", "3"):
             monkeypatch.setenv("PTMI_RENDER_LANES", lanes)
             ctx = Context(0)
             try:
@@ -388,7 +388,8 @@ def test_two_lanes_equal_one(monkeypatch):
             finally:
                 ctx.close()
         assert bool((frames[0][1] == spp + 3).all())
-        assert torch.equal(frames[0][0], frames[1][0]) and torch.equal(frames[0][1], frames[1][1])
+        for a, c in frames[1:]:
+            assert torch.equal(frames[0][0], a) and torch.equal(frames[0][1], c)
 
 
 def test_full_size_frame_properties(gpu_ctx):
