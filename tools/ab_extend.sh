@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B the extend kernel variants: parity tests + bench per variant.  usage: tools/ab_extend.sh "0 1 2"
+# A/B the extend kernel variants: parity tests + bench per variant.  usage: tools/ab_extend.sh "0 1"  (0 = one-shot kernels, 1 = vote-scheduled persistent kernels)
 set -u
 for v in $1; do
   echo "=== variant $v"
