@@ -129,6 +129,61 @@ def test_render_frame_sharded_world_2_with_stub_comm():
     assert ok == (True, True)
 
 
+def _agree_worker(rank, world, port, case, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class _Comm:                                             # what PtmiComm(ctx, rank, world, id) would be
+        kind, note, closed = "rccl", "", False
+
+        def __init__(self, ctx, r, w, uid):
+            if case == "init_fails_on_rank_1" and r == 1:
+                raise RuntimeError("ncclCommInitRank: unhandled system error")
+            assert uid == bytes(range(128)), "every rank must receive rank 0's id"
+
+        def close(self):
+            type(self).closed = True
+
+        @staticmethod
+        def unique_id():
+            if case == "load_fails_on_rank_1" and rank == 1:
+                raise RuntimeError("RCCL unavailable: librccl.so not found")
+            return bytes(range(128)) if rank == 0 else bytes(128)          # only rank 0's id may be used
+
+    sharded.PtmiComm = _Comm
+    renderer = type("R", (), {"ctx": None})()
+    comm = sharded.make_comm(renderer, rank, world, dist, torch.device("cpu"))
+    q.put((rank, comm.kind, comm.note, _Comm.closed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["all_fine", "load_fails_on_rank_1", "init_fails_on_rank_1"])
+def test_ranks_agree_on_the_communicator(case):
+    """make_comm's outcome is collective: if one rank cannot load RCCL through the C ABI, or its communicator fails to
+    initialise, EVERY rank falls back to the launcher's process group (a rank that went ahead alone would hang in the
+    next collective); the rank that got a communicator closes it again."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    kinds = [g[1] for g in got]
+    if case == "all_fine":
+        assert kinds == ["rccl", "rccl"]
+    else:
+        assert kinds == ["dist", "dist"]
+        assert "rank 1" in got[1][2] and got[0][2]                 # rank 1 knows why, rank 0 knows it was another rank
+        if case == "init_fails_on_rank_1":
+            assert got[0][3] is True                               # rank 0's communicator was closed again
+
+
 def test_comm_entry_points_fail_cleanly_without_rccl():
     """The comm entry points bind RCCL at run time; when it cannot be loaded they return PTMI_ERR_COMM with a reason,
     and bad arguments are refused before that.  (A child process: the binding is made once per process.)"""
