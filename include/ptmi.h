@@ -303,7 +303,8 @@ int ptmi_reduce_frame(ptmi_ctx *ctx, const float *send_accum, const uint32_t *se
  * [spp_begin, spp_begin + spp_count), and reduces onto `root`, whose buffers then hold the frame -- bit-identical to
  * ptmi_render_dev of the whole frame into zeroed buffers on one GPU.  To continue a frame over several calls keep
  * per-rank buffers with ptmi_render_rows_dev and reduce once with ptmi_reduce_frame (out of place).  If a rank's
- * render fails it returns the error without joining the reduce: the host must then tear the job down. */
+ * render fails it still joins the reduce (the other ranks are already waiting in it) and then returns its error: no
+ * rank hangs, the frame on `root` is not valid, and the host learns so from the failing rank's return code. */
 int ptmi_render_sharded(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t row_block,
                         uint32_t spp_begin, uint32_t spp_count, float *accum_rgb, uint32_t *counts, int root,
                         void *stream);

@@ -201,7 +201,11 @@ extern "C" int ptmi_render_sharded(ptmi_ctx *ctx, const PtCamera *camera, const 
     PTMI_HIP(ctx, hipMemsetAsync(counts, 0, npix * 4, s));
     int rc = ptmi_render_rows_dev(ctx, camera, params, row_block, ctx->comm_rank, ctx->comm_nranks, spp_begin, spp_count, accum_rgb,
                                   counts, stream);
-    if (rc) return rc;
-    if (ctx->comm_nranks == 1) return PTMI_OK;
-    return ptmi_reduce_frame(ctx, accum_rgb, counts, accum_rgb, counts, params->width, params->height, root, stream);
+    if (ctx->comm_nranks == 1) return rc;
+    // A rank whose render failed still takes part in the reduce (with whatever its buffers hold): the other ranks are
+    // already on their way into it and would wait for ever.  The failing rank reports its error; the frame is not valid.
+    std::string render_err = rc ? ctx->err : std::string();
+    int rr = ptmi_reduce_frame(ctx, accum_rgb, counts, accum_rgb, counts, params->width, params->height, root, stream);
+    if (rc) { ctx->err = render_err; return rc; }
+    return rr;
 }
