@@ -246,7 +246,7 @@ int ptmi_render_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *param
 /* One GPU's share of a frame in ONE call: the rows y with (y / row_block) % nshards == shard, full width, added
  * into FULL-FRAME device buffers accum_rgb[height*width*3] / counts[height*width] (other rows untouched).  The
  * reference deals 64x64 tiles to goroutines (main.go:454-491, :935-937); a GPU wants its whole share at once --
- * the wavefront loop costs ~0.3 ms per iteration whatever the number of paths in it -- so the shard is an
+ * every call ends by draining its own path pool, 10-15 iterations on fewer and fewer paths -- so the shard is an
  * interleave of row blocks, and a sum of the shards' buffers (RCCL reduce) is the frame. */
 int ptmi_render_rows_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t row_block,
                          int32_t shard, int32_t nshards, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
