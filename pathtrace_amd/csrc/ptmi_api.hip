@@ -283,6 +283,7 @@ extern "C" void ptmi_destroy(ptmi_ctx *ctx) {
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
 }
 
@@ -557,30 +558,66 @@ extern "C" int ptmi_any_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const float *
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// The host-pointer forms move 40 (29) bytes per ray over the link, more time than the walk itself takes, so the batch
+// goes through in chunks on two streams: while one chunk is walked, the next one's rays are on their way in and the
+// previous one's answers on their way out (each direction has its own DMA engines).  Every chunk has its own part of
+// the staging buffer and its own cursor line, so the two streams never share state.  That is for page-locked caller
+// buffers (16.7 M rays: 15 ms = 45 GB/s over the link, against 35 ms unpipelined).
+constexpr uint64_t HOST_CHUNK_RAYS = 1ull << 21;
+
+template <typename Launch, typename CopyOut>
+static int host_batch(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n, size_t out_bytes_per_ray,
+                      Launch launch, CopyOut copy_out) {
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->stream2) PTMI_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    const size_t b3 = align_up(n * 12, 256), b1 = align_up(n * 4, 256), bo = align_up(n * out_bytes_per_ray, 256);
+    int rc = ensure_stage(ctx, 2 * b3 + b1 + bo);
+    if (rc) return rc;
+    char *base = (char *)ctx->d_stage;
+    float *dO = (float *)base, *dD = (float *)(base + b3), *dT = (float *)(base + 2 * b3);
+    char *dOut = base + 2 * b3 + b1;
+    // pageable memory gains nothing from chunks (the runtime stages it synchronously, and many small staged copies are
+    // slower than a few large ones: measured -15 %): it goes through as one chunk, as before
+    hipPointerAttribute_t attr{};
+    const bool pinned = hipPointerGetAttributes(&attr, o_xyz) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    const uint64_t chunk = pinned ? HOST_CHUNK_RAYS : n;
+    int k = 0;
+    for (uint64_t first = 0; first < n; first += chunk, ++k) {
+        const uint64_t m = std::min<uint64_t>(chunk, n - first);
+        hipStream_t s = (k & 1) ? ctx->stream2 : ctx->stream;
+        PTMI_HIP(ctx, hipMemcpyAsync(dO + 3 * first, o_xyz + 3 * first, m * 12, hipMemcpyHostToDevice, s));
+        PTMI_HIP(ctx, hipMemcpyAsync(dD + 3 * first, d_xyz + 3 * first, m * 12, hipMemcpyHostToDevice, s));
+        PTMI_HIP(ctx, hipMemcpyAsync(dT + first, tmax + first, m * 4, hipMemcpyHostToDevice, s));
+        rc = launch(dO + 3 * first, dD + 3 * first, dT + first, m, dOut, first, s);
+        if (rc) break;
+        rc = copy_out(dOut, first, m, s);
+        if (rc) break;
+    }
+    hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = hipStreamSynchronize(ctx->stream2);
+    if (rc) return rc;
+    PTMI_HIP(ctx, e1);
+    PTMI_HIP(ctx, e2);
+    return PTMI_OK;
+}
+
 extern "C" int ptmi_closest_hit(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n,
                                 int32_t *prim_id, float *t) {
     if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_closest_hit: ctx is null");
     if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_closest_hit: no BVH uploaded");
     if (n == 0) return PTMI_OK;
     if (!o_xyz || !d_xyz || !tmax || !prim_id || !t) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_closest_hit: null buffer");
-    PTMI_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t b3 = align_up(n * 12, 256), b1 = align_up(n * 4, 256);
-    int rc = ensure_stage(ctx, 2 * b3 + 3 * b1);
-    if (rc) return rc;
-    char *base = (char *)ctx->d_stage;
-    float *dO = (float *)base, *dD = (float *)(base + b3), *dT = (float *)(base + 2 * b3);
-    int32_t *dP = (int32_t *)(base + 2 * b3 + b1);
-    float *dt = (float *)(base + 2 * b3 + 2 * b1);
-    hipStream_t s = ctx->stream;
-    PTMI_HIP(ctx, hipMemcpyAsync(dO, o_xyz, n * 12, hipMemcpyHostToDevice, s));
-    PTMI_HIP(ctx, hipMemcpyAsync(dD, d_xyz, n * 12, hipMemcpyHostToDevice, s));
-    PTMI_HIP(ctx, hipMemcpyAsync(dT, tmax, n * 4, hipMemcpyHostToDevice, s));
-    rc = dispatch_extend(ctx, ctx_scratch(ctx), dO, dD, dT, n, dP, dt, s);
-    if (rc) return rc;
-    PTMI_HIP(ctx, hipMemcpyAsync(prim_id, dP, n * 4, hipMemcpyDeviceToHost, s));
-    PTMI_HIP(ctx, hipMemcpyAsync(t, dt, n * 4, hipMemcpyDeviceToHost, s));
-    PTMI_HIP(ctx, hipStreamSynchronize(s));
-    return PTMI_OK;
+    const size_t half = align_up(n * 4, 256);          // staged answers: prim ids, then t
+    return host_batch(
+        ctx, o_xyz, d_xyz, tmax, n, 8,
+        [&](const float *dO, const float *dD, const float *dT, uint64_t m, char *dOut, uint64_t first, hipStream_t s) {
+            return dispatch_extend(ctx, ctx_scratch(ctx), dO, dD, dT, m, (int32_t *)dOut + first, (float *)(dOut + half) + first, s);
+        },
+        [&](char *dOut, uint64_t first, uint64_t m, hipStream_t s) -> int {
+            PTMI_HIP(ctx, hipMemcpyAsync(prim_id + first, (int32_t *)dOut + first, m * 4, hipMemcpyDeviceToHost, s));
+            PTMI_HIP(ctx, hipMemcpyAsync(t + first, (float *)(dOut + half) + first, m * 4, hipMemcpyDeviceToHost, s));
+            return PTMI_OK;
+        });
 }
 
 extern "C" int ptmi_any_hit(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n,
@@ -589,22 +626,15 @@ extern "C" int ptmi_any_hit(ptmi_ctx *ctx, const float *o_xyz, const float *d_xy
     if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_any_hit: no BVH uploaded");
     if (n == 0) return PTMI_OK;
     if (!o_xyz || !d_xyz || !tmax || !occluded) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_any_hit: null buffer");
-    PTMI_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t b3 = align_up(n * 12, 256), b1 = align_up(n * 4, 256);
-    int rc = ensure_stage(ctx, 2 * b3 + 2 * b1);
-    if (rc) return rc;
-    char *base = (char *)ctx->d_stage;
-    float *dO = (float *)base, *dD = (float *)(base + b3), *dT = (float *)(base + 2 * b3);
-    uint8_t *dOcc = (uint8_t *)(base + 2 * b3 + b1);
-    hipStream_t s = ctx->stream;
-    PTMI_HIP(ctx, hipMemcpyAsync(dO, o_xyz, n * 12, hipMemcpyHostToDevice, s));
-    PTMI_HIP(ctx, hipMemcpyAsync(dD, d_xyz, n * 12, hipMemcpyHostToDevice, s));
-    PTMI_HIP(ctx, hipMemcpyAsync(dT, tmax, n * 4, hipMemcpyHostToDevice, s));
-    rc = dispatch_connect(ctx, ctx_scratch(ctx), dO, dD, dT, n, dOcc, s);
-    if (rc) return rc;
-    PTMI_HIP(ctx, hipMemcpyAsync(occluded, dOcc, n, hipMemcpyDeviceToHost, s));
-    PTMI_HIP(ctx, hipStreamSynchronize(s));
-    return PTMI_OK;
+    return host_batch(
+        ctx, o_xyz, d_xyz, tmax, n, 1,
+        [&](const float *dO, const float *dD, const float *dT, uint64_t m, char *dOut, uint64_t first, hipStream_t s) {
+            return dispatch_connect(ctx, ctx_scratch(ctx), dO, dD, dT, m, (uint8_t *)dOut + first, s);
+        },
+        [&](char *dOut, uint64_t first, uint64_t m, hipStream_t s) -> int {
+            PTMI_HIP(ctx, hipMemcpyAsync(occluded + first, (uint8_t *)dOut + first, m, hipMemcpyDeviceToHost, s));
+            return PTMI_OK;
+        });
 }
 
 // ------------------------------------------------------------------------------------ counters

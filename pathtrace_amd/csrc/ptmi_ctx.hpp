@@ -55,6 +55,7 @@ struct ptmi_ctx {
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // second stream of the chunked host-pointer batches (created on first use)
 
     // scene + wavefront integrator state (ptmi_render.hip)
     struct RenderState *render = nullptr;

@@ -224,3 +224,37 @@ def test_full_size_batch_properties(gpu_ctx, monkeypatch):
     op, ot, _ = orc.closest_hit(np.ascontiguousarray(o[idx]), np.ascontiguousarray(d[idx]), 1000.0)
     oocc, _ = orc.any_hit(np.ascontiguousarray(o[idx]), np.ascontiguousarray(d[idx]), 1000.0)
     assert np.array_equal(P[idx], op) and bits_equal(T[idx], ot) and np.array_equal(OCC[idx].astype(bool), oocc)
+
+
+def test_host_batches_from_page_locked_buffers_go_through_in_chunks(gpu_ctx):
+    """ptmi_closest_hit / ptmi_any_hit with page-locked caller buffers run as 2 M-ray chunks on two streams (copies
+    overlapped with the walk); 2.5 chunks here.  The answers equal the one-chunk path (pageable buffers) bit for bit and
+    the oracle on a sample."""
+    import ctypes as C
+    import torch
+    from pathtrace_amd import _lib
+    lib = _lib.load()
+    v, f = scenes.make_soup(20000, 31)
+    box = BuildBVH(v, f)
+    bvh = ConstructLinearBVH(box, ctx=gpu_ctx)
+    n = (5 << 20) + 12345
+    o, d = random_rays(v, n, 9)
+    tmax = np.full(n, 1000.0, np.float32)
+    tmax[::7] = 3.0                                              # a mix of ranges
+    hit, t_ref, prim_ref = bvh.CheckIntersection((o, d), tmax)   # numpy arrays: pageable, one chunk
+    occ_ref = bvh.QuickCheckIntersection((o, d), tmax)
+    pin = lambda x: torch.from_numpy(np.ascontiguousarray(x)).pin_memory()
+    O, D, T = pin(o), pin(d), pin(tmax)
+    P = torch.full((n,), -7, dtype=torch.int32).pin_memory()
+    Tt = torch.full((n,), -7.0, dtype=torch.float32).pin_memory()
+    Oc = torch.full((n,), 9, dtype=torch.uint8).pin_memory()
+    fp = lambda x: C.cast(x.data_ptr(), C.POINTER(C.c_float))
+    h = gpu_ctx.handle
+    _lib.check(lib.ptmi_closest_hit(h, fp(O), fp(D), fp(T), n, C.cast(P.data_ptr(), C.POINTER(C.c_int32)), fp(Tt)), h)
+    _lib.check(lib.ptmi_any_hit(h, fp(O), fp(D), fp(T), n, C.cast(Oc.data_ptr(), C.POINTER(C.c_uint8))), h)
+    assert np.array_equal(P.numpy(), prim_ref) and bits_equal(Tt.numpy(), t_ref)
+    assert np.array_equal(Oc.numpy().astype(bool), np.asarray(occ_ref).astype(bool))
+    idx = np.arange(0, n, 257)
+    orc = oracle_lib.OracleBVH(v, f, linear=box.linear())
+    op, ot, _ = orc.closest_hit(np.ascontiguousarray(o[idx]), np.ascontiguousarray(d[idx]), np.ascontiguousarray(tmax[idx]))
+    assert np.array_equal(P.numpy()[idx], op) and bits_equal(Tt.numpy()[idx], ot)
