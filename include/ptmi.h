@@ -267,6 +267,23 @@ int ptmi_render_samples(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *p
 int ptmi_to_rgba(ptmi_ctx *ctx, const float *accum_rgb, const uint32_t *counts, int32_t width, int32_t height,
                  uint8_t *rgba);
 
+/* Per-kernel timing of the render calls -- the counterpart of the reference's runtime/pprof CPU profile around its
+ * workers (main.go:797-822).  While enabled, every kernel launch of the wavefront loop is bracketed by a pair of HIP
+ * events on its stream, a pass runs as ONE loop (so that the kernels do not overlap and their times add up to the
+ * wall time), and the totals accumulate until they are reset.  Off by default: the events cost a few per cent. */
+typedef struct {
+    double prepare_ms;     /* loop bookkeeping kernels                                  */
+    double generate_ms;    /* camera rays                      (main.go:861-874)        */
+    double extend_ms;      /* closest-hit walks                (tracer.go:34-35, :226-256) */
+    double connect_ms;     /* shadow-ray walks                 (QuickCheckIntersection) */
+    double shade_ms;       /* TraceRay / HandleDiffuseMaterial / HandleReflectiveMaterial */
+    double accumulate_ms;  /* Pixel.AddSample sums             (renderer.go:59-61)      */
+    uint64_t iterations;   /* wavefront iterations enqueued (the last few of a call are empty) */
+    uint64_t launches;     /* kernel launches timed                                     */
+} PtRenderProfile;
+int ptmi_set_profiling(ptmi_ctx *ctx, int enabled);     /* also resets the totals */
+int ptmi_render_profile(ptmi_ctx *ctx, PtRenderProfile *out);
+
 /* ------------------------------------------------------------------ multi-GPU (RCCL over xGMI) */
 
 /* No counterpart in the reference: its tile workers are goroutines of one process that write disjoint Pixels of one

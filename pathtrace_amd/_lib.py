@@ -36,6 +36,12 @@ class PtCounters(C.Structure):
                 ("samples", C.c_uint64)]
 
 
+class PtRenderProfile(C.Structure):
+    """Per-kernel time of the render calls since ptmi_set_profiling(1), in milliseconds."""
+    _fields_ = [("prepare_ms", C.c_double), ("generate_ms", C.c_double), ("extend_ms", C.c_double), ("connect_ms", C.c_double),
+                ("shade_ms", C.c_double), ("accumulate_ms", C.c_double), ("iterations", C.c_uint64), ("launches", C.c_uint64)]
+
+
 class PtCamera(C.Structure):
     """camera.go:9-15"""
     _fields_ = [("position", C.c_float * 3), ("forward", C.c_float * 3), ("right", C.c_float * 3),
@@ -80,6 +86,8 @@ SIGNATURES = {
     "ptmi_set_counting": (C.c_int, [_P, C.c_int]),
     "ptmi_reset_counters": (C.c_int, [_P]),
     "ptmi_counters": (C.c_int, [_P, C.POINTER(PtCounters)]),
+    "ptmi_set_profiling": (C.c_int, [_P, C.c_int]),
+    "ptmi_render_profile": (C.c_int, [_P, C.POINTER(PtRenderProfile)]),
     "ptmi_upload_scene": (C.c_int, [_P, _P, _U64, _U32, _F, _P, _U64, _P, C.POINTER(C.c_uint16), _P]),
     "ptmi_upload_textures": (C.c_int, [_P, _F, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _U32]),
     "ptmi_render": (C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), C.c_int32, C.c_int32, C.c_int32,
@@ -121,6 +129,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C pathtrace_amd/csrc` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64, libptmi.so asks for the ROCm installation's.
+    # Whichever is loaded first serves both (same SONAME) -- but if libptmi comes first and torch later brings its own
+    # copy, the second runtime finds no GPU ("No HIP GPUs are available").  The host side uses torch for device
+    # buffers anyway, so it goes first when it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -284,6 +284,8 @@ extern "C" void ptmi_destroy(ptmi_ctx *ctx) {
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (auto &sp : ctx->prof_open) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
     delete ctx;
 }
 

@@ -79,6 +79,14 @@ struct ptmi_ctx {
     int vote_tri_bias = -8;             // inner step wins the vote when nI + bias >= nT
     int vote_chunk = 128;               // rays reserved per cursor atomic (multiple of 64)
 
+    // per-kernel timing of the render calls (ptmi_set_profiling): totals in ms, by PROF_* class, and event bookkeeping
+    bool profiling = false;
+    double prof_ms[8] = {};
+    uint64_t prof_iterations = 0, prof_launches = 0;
+    struct ProfSpan { int cls; hipEvent_t a, b; };
+    std::vector<ProfSpan> prof_open;            // spans of the pass in flight
+    std::vector<hipEvent_t> prof_free;          // events ready for reuse
+
     // work counters
     bool counting = false;
     unsigned long long *d_counters = nullptr;

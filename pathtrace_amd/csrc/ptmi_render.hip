@@ -1251,6 +1251,36 @@ static uint32_t vote_from_for(const ptmi_ctx *ctx, int per_cu) {
 }
 constexpr uint32_t VOTE_NEVER = 0xFFFFFFFFu;
 
+// ---- per-kernel timing (ptmi_set_profiling) ----
+enum { PROF_PREPARE = 0, PROF_GENERATE, PROF_EXTEND, PROF_CONNECT, PROF_SHADE, PROF_ACCUMULATE, PROF_CLASSES };
+static hipEvent_t prof_event(ptmi_ctx *ctx) {
+    if (!ctx->prof_free.empty()) { hipEvent_t e = ctx->prof_free.back(); ctx->prof_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return e;
+}
+// brackets what `launch` enqueues on stream s with two events when profiling is on
+template <typename F>
+static void timed(ptmi_ctx *ctx, int cls, hipStream_t s, F launch) {
+    if (!ctx->profiling) { launch(); return; }
+    hipEvent_t a = prof_event(ctx), b = prof_event(ctx);
+    if (a) (void)hipEventRecord(a, s);
+    launch();
+    if (b) (void)hipEventRecord(b, s);
+    if (a && b) ctx->prof_open.push_back({cls, a, b});
+    else { if (a) ctx->prof_free.push_back(a); if (b) ctx->prof_free.push_back(b); }
+}
+// after the pass's stream has been synchronised: turn the spans into milliseconds
+static void prof_collect(ptmi_ctx *ctx) {
+    for (const auto &sp : ctx->prof_open) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { ctx->prof_ms[sp.cls] += (double)ms; ctx->prof_launches++; }
+        else (void)hipGetLastError();
+        ctx->prof_free.push_back(sp.a); ctx->prof_free.push_back(sp.b);
+    }
+    ctx->prof_open.clear();
+}
+
 // One iteration of the wavefront loop on queue buffer `cur`, enqueued without knowing its sizes (IterArgs); the grids
 // cover the most paths the call can have in flight (the pool, or all of the call's samples if those are fewer).
 template <int STACK>
@@ -1258,8 +1288,10 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
                                hipStream_t s) {
     const uint64_t most = std::min<uint64_t>(pl.cap, lane_total);
     const unsigned cap_wgs = (unsigned)((most + 255) / 256), cap_waves = (unsigned)((most + WAVE - 1) / WAVE);
-    hipLaunchKernelGGL(iter_prep_kernel, dim3(1), dim3(64), 0, s, pl, cur, (unsigned long long)lane_total, ctx->d_counters);
-    hipLaunchKernelGGL(generate_kernel, dim3(cap_wgs), dim3(256), 0, s, pl, ra, cur);
+    if (ctx->profiling) ctx->prof_iterations++;
+    timed(ctx, PROF_PREPARE, s, [&] {
+        hipLaunchKernelGGL(iter_prep_kernel, dim3(1), dim3(64), 0, s, pl, cur, (unsigned long long)lane_total, ctx->d_counters); });
+    timed(ctx, PROF_GENERATE, s, [&] { hipLaunchKernelGGL(generate_kernel, dim3(cap_wgs), dim3(256), 0, s, pl, ra, cur); });
     // extend
     uint32_t vote_from = VOTE_NEVER;
     if (!sc.has_bh && ra.p.max_steps == 1 && ctx->extend_vote) {
@@ -1267,17 +1299,19 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
         vote_from = vote_from_for(ctx, per_cu);
         const unsigned pgrid = (unsigned)std::min<uint64_t>(cap_waves, (uint64_t)ctx->num_cus * per_cu);
         if (most >= vote_from)          // a call this small never has a queue that long: one launch less per iteration
-            hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, cur, vote_from,
-                               ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk);
+            timed(ctx, PROF_EXTEND, s, [&] {
+                hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, cur, vote_from,
+                                   ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk); });
     }
     if (vote_from > 0) {
         const unsigned grid = (unsigned)std::min<uint64_t>(cap_waves, ((uint64_t)vote_from + WAVE - 1) / WAVE);
-        if (sc.has_bh)
-            hipLaunchKernelGGL((render_extend_kernel<STACK, true>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, sc, ra, cur,
-                               vote_from, ctx->d_counters);
-        else
-            hipLaunchKernelGGL((render_extend_kernel<STACK, false>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, sc, ra, cur,
-                               vote_from, ctx->d_counters);
+        timed(ctx, PROF_EXTEND, s, [&] {
+            if (sc.has_bh)
+                hipLaunchKernelGGL((render_extend_kernel<STACK, true>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, sc, ra, cur,
+                                   vote_from, ctx->d_counters);
+            else
+                hipLaunchKernelGGL((render_extend_kernel<STACK, false>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, sc, ra, cur,
+                                   vote_from, ctx->d_counters); });
     }
     // connect
     const uint64_t ray_waves = (most * (uint64_t)pl.nshadow + WAVE - 1) / WAVE;
@@ -1287,16 +1321,18 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
         vote_from = vote_from_for(ctx, per_cu);
         const unsigned pgrid = (unsigned)std::min<uint64_t>(ray_waves, (uint64_t)ctx->num_cus * per_cu);
         if (most * (uint64_t)pl.nshadow >= vote_from)
-            hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, vote_from,
-                               ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk);
+            timed(ctx, PROF_CONNECT, s, [&] {
+                hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, vote_from,
+                                   ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk); });
     }
     if (vote_from > 0) {
         const unsigned grid = (unsigned)std::min<uint64_t>(ray_waves, ((uint64_t)vote_from + WAVE - 1) / WAVE);
-        hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, vote_from, ctx->d_counters);
+        timed(ctx, PROF_CONNECT, s, [&] {
+            hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, vote_from, ctx->d_counters); });
     }
     // shade
     const size_t ray_lds = (size_t)(SRW * pl.nshadow - 1) * 256 * sizeof(float);
-    hipLaunchKernelGGL(shade_kernel, dim3(cap_wgs), dim3(256), ray_lds, s, pl, sc, ra, cur, ctx->d_counters);
+    timed(ctx, PROF_SHADE, s, [&] { hipLaunchKernelGGL(shade_kernel, dim3(cap_wgs), dim3(256), ray_lds, s, pl, sc, ra, cur, ctx->d_counters); });
     PTMI_HIP(ctx, hipGetLastError());
     return PTMI_OK;
 }
@@ -1358,7 +1394,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     // lane's queues get shorter).  The image does not depend on the split.
     const uint64_t tree_bytes = ctx->packed_inner * 64 + ctx->packed_tris * 48;
     const int want_lanes = ctx->render_lanes < 0 ? (tree_bytes <= (32ull << 20) ? 2 : 1) : ctx->render_lanes;
-    const int lanes = (want_lanes >= 2 && max_total >= (1ull << 22)) ? std::min(want_lanes, (int)RenderState::MAX_LANES) : 1;
+    const int lanes = (want_lanes >= 2 && max_total >= (1ull << 22) && !ctx->profiling) ? std::min(want_lanes, (int)RenderState::MAX_LANES) : 1;
     uint32_t cap = (uint32_t)std::min<uint64_t>({(max_total + lanes - 1) / lanes, (uint64_t)ctx->pool_paths / lanes, by_budget / lanes});
     cap = (cap + 255) / 256 * 256;
     // the per-sample output buffer first (its size is fixed by the request), then as large a pool as fits
@@ -1430,7 +1466,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             ln.active = ln.total > 0;
             if (!ln.active) continue;
             const uint32_t n0 = (uint32_t)std::min<uint64_t>(ln.pl.cap, ln.total);
-            hipLaunchKernelGGL(iter_init_kernel, dim3((n0 + 255) / 256), dim3(256), 0, ln.st, ln.pl, n0);
+            timed(ctx, PROF_PREPARE, ln.st, [&] { hipLaunchKernelGGL(iter_init_kernel, dim3((n0 + 255) / 256), dim3(256), 0, ln.st, ln.pl, n0); });
             PTMI_HIP(ctx, hipGetLastError());
         }
         auto enqueue_batch = [&](Lane &ln, int slot) -> int {
@@ -1484,9 +1520,14 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             PTMI_HIP(ctx, hipMemcpyAsync(out_samples_host, rs->d_out, ra.total * 12, hipMemcpyDeviceToHost, s));
             PTMI_HIP(ctx, hipStreamSynchronize(s));
         } else {
-            hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rs->d_out,
-                               (uint32_t)npix, chunk, d_accum, d_counts, ra, rows_mode ? prm->width : 0);
+            timed(ctx, PROF_ACCUMULATE, s, [&] {
+                hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rs->d_out,
+                                   (uint32_t)npix, chunk, d_accum, d_counts, ra, rows_mode ? prm->width : 0); });
             PTMI_HIP(ctx, hipGetLastError());
+        }
+        if (ctx->profiling) {
+            PTMI_HIP(ctx, hipStreamSynchronize(s));
+            prof_collect(ctx);
         }
     }
     return PTMI_OK;
@@ -1649,5 +1690,25 @@ extern "C" int ptmi_to_rgba(ptmi_ctx *ctx, const float *accum_rgb, const uint32_
             }
             o[3] = 255;
         }
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_set_profiling(ptmi_ctx *ctx, int enabled) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_set_profiling: ctx is null");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    PTMI_HIP(ctx, hipDeviceSynchronize());
+    prof_collect(ctx);
+    ctx->profiling = enabled != 0;
+    for (double &v : ctx->prof_ms) v = 0.0;
+    ctx->prof_iterations = ctx->prof_launches = 0;
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_render_profile(ptmi_ctx *ctx, PtRenderProfile *out) {
+    if (!ctx || !out) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_profile: null argument");
+    out->prepare_ms = ctx->prof_ms[PROF_PREPARE]; out->generate_ms = ctx->prof_ms[PROF_GENERATE];
+    out->extend_ms = ctx->prof_ms[PROF_EXTEND]; out->connect_ms = ctx->prof_ms[PROF_CONNECT];
+    out->shade_ms = ctx->prof_ms[PROF_SHADE]; out->accumulate_ms = ctx->prof_ms[PROF_ACCUMULATE];
+    out->iterations = ctx->prof_iterations; out->launches = ctx->prof_launches;
     return PTMI_OK;
 }

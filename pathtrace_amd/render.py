@@ -108,6 +108,16 @@ class Renderer:
         check(self._lib.ptmi_upload_textures(self.ctx.handle, _ptr(uv, C.c_float), len(textures), _ptr(w, C.c_int32),
                                              _ptr(h, C.c_int32), _ptr(px, C.c_uint32)), self.ctx.handle)
 
+    def set_profiling(self, enabled=True):
+        """Per-kernel HIP-event timing of the render calls (the reference's pprof hook, main.go:797-822); resets the totals."""
+        check(self._lib.ptmi_set_profiling(self.ctx.handle, 1 if enabled else 0), self.ctx.handle)
+
+    def profile(self) -> dict:
+        """Milliseconds per kernel class since set_profiling(True), plus the iteration and launch counts."""
+        p = _lib.PtRenderProfile()
+        check(self._lib.ptmi_render_profile(self.ctx.handle, C.byref(p)), self.ctx.handle)
+        return {name: getattr(p, name) for name, _ in p._fields_}
+
     @staticmethod
     def new_framebuffer(width, height) -> Framebuffer:
         return Framebuffer(np.zeros((height, width, 3), np.float32), np.zeros((height, width), np.uint32))

@@ -363,6 +363,36 @@ def test_checkpoint_and_resume(gpu_ctx, tmp_path):
     assert Framebuffer.load(tmp_path / "loop.npz").samples_done == 4
 
 
+def test_render_profile_adds_up_and_changes_nothing(gpu_ctx):
+    """ptmi_set_profiling brackets every kernel of the wavefront loop with HIP events: the per-class times are positive,
+    add up to no more than the wall time of the calls, every enqueued launch is accounted for, and the sums of the frame
+    are those of an unprofiled render."""
+    import time
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    p = make_params(160, 120, bounces=2, seed=5)
+    r = Renderer(sc, ctx=gpu_ctx)
+    plain = r.new_framebuffer(160, 120)
+    r.render_tile(plain, p, sc.camera, spp=8)
+    r.set_profiling(True)
+    try:
+        assert r.profile()["launches"] == 0
+        fb = r.new_framebuffer(160, 120)
+        t0 = time.perf_counter()
+        r.render_tile(fb, p, sc.camera, spp=8)
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        prof = r.profile()
+    finally:
+        r.set_profiling(False)
+    assert np.array_equal(fb.accum.view(np.uint32), plain.accum.view(np.uint32)) and np.array_equal(fb.counts, plain.counts)
+    parts = [prof[k] for k in ("prepare_ms", "generate_ms", "extend_ms", "connect_ms", "shade_ms", "accumulate_ms")]
+    assert all(v > 0.0 for v in parts), prof
+    assert sum(parts) <= wall_ms, (prof, wall_ms)
+    # per iteration: prepare, generate, extend, connect, shade (the shared context forces the vote-scheduled kernels, so
+    # one traversal kernel each); per call: the start-of-call kernel and accumulate
+    assert prof["iterations"] >= 4 and prof["launches"] == 5 * prof["iterations"] + 2, prof
+    assert r.profile()["launches"] == 0          # switched off and reset
+
+
 def test_two_lanes_equal_one(monkeypatch):
     """PTMI_RENDER_LANES=n deals the samples of a pass in blocks of 65 536 to n independent wavefront loops on n
     streams (each with its share of the pool); the sums equal the one-loop render bit for bit.  The two sizes end in a

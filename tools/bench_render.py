@@ -14,6 +14,7 @@ ap.add_argument("--scene", default="c3"); ap.add_argument("--width", type=int, d
 ap.add_argument("--height", type=int, default=1080); ap.add_argument("--spp", type=int, default=16)
 ap.add_argument("--bounces", type=int, default=2); ap.add_argument("--png", default=None)
 ap.add_argument("--level", type=int, default=6)
+ap.add_argument("--profile", action="store_true", help="per-kernel HIP-event times of the timed frame (ptmi_set_profiling: one lane)")
 a = ap.parse_args()
 if a.scene == "c4":
     sc = scenes.c4_scene(); p = make_params(a.width, a.height, bounces=a.bounces, seed=1)
@@ -28,10 +29,15 @@ acc = torch.zeros((a.height, a.width, 3), dtype=torch.float32, device=dev); cnt 
 stream = torch.cuda.current_stream().cuda_stream
 r.render_device(acc, cnt, p, sc.camera, spp=a.spp, stream=stream)  # warm-up at full size: the pool and the sample buffer are allocated here
 acc.zero_(); cnt.zero_(); r.bvh.reset_counters(); torch.cuda.synchronize()
+if a.profile: r.set_profiling(True)
 t0 = time.time(); r.render_device(acc, cnt, p, sc.camera, spp=a.spp, stream=stream); torch.cuda.synchronize(); dt = time.time() - t0
 c = r.bvh.counters(); n = a.width * a.height * a.spp
 print(f"{n} samples in {dt*1e3:.1f} ms = {n/dt/1e6:.2f} Msamples/s; closest {c.closest_queries/dt/1e6:.1f} Mq/s, any {c.any_queries/dt/1e6:.1f} Mq/s, "
       f"diffuse events {c.diffuse_events/dt/1e6:.1f} M/s; per sample: {c.closest_queries/n:.2f} closest, {c.any_queries/n:.2f} any")
+if a.profile:
+    pr = r.profile(); r.set_profiling(False)
+    print("profile (ms): " + ", ".join(f"{k[:-3]} {pr[k]:.2f}" for k in pr if k.endswith("_ms")) +
+          f"; sum {sum(pr[k] for k in pr if k.endswith('_ms')):.2f} of {dt*1e3:.1f} wall; {pr['iterations']} iterations, {pr['launches']} launches")
 if a.png:
     from write_png import write_png
     from pathtrace_amd.render import Framebuffer
