@@ -988,29 +988,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // ------------------------------------------------------------------------------------------ accumulate
-// Pixel.AddSample's running sums (renderer.go:29, 59-61): R += c.X ... in sample order.
-// The per-sample output is pixel-major ([pixel][sample][3]) like the sample numbering, so a thread's reads are 12 bytes
-// every 3 KB (1.2 TB/s, 1.3 % of a C3 frame).  Tried and dropped: sample-major output (shade's writes of samples that
-// finish together scatter instead: no gain) and sample-major numbering with it (neighbouring samples are then
-// neighbouring pixels instead of one pixel's jittered rays, and the traversal kernels lose more coherence than
-// accumulate gains: C3 -3 %, the 10 M-triangle scene -9 %).
+// Pixel.AddSample's running sums (renderer.go:29, 59-61): R += c.X ... in sample order, one thread per pixel.
+// The per-sample output is pixel-major ([pixel][sample][3]) like the sample numbering, so read directly a thread's
+// samples are 12 bytes every 3 KB (1.2 TB/s, 5.4 ms per C3 frame; staged: 2.8 ms).  The workgroup therefore stages tiles of ACC_TILE samples of its 256
+// pixels through LDS: the loads walk each pixel's 12 * ACC_TILE contiguous bytes with consecutive lanes (whole sectors),
+// and every thread then adds ITS pixel's samples from LDS in sample order -- the same additions in the same order.
+// Tried and dropped: sample-major output (shade's writes of samples that finish together scatter instead: no gain) and
+// sample-major numbering with it (neighbouring samples are then neighbouring pixels instead of one pixel's jittered
+// rays, and the traversal kernels lose more coherence than accumulate gains: C3 -3 %, the 10 M-triangle scene -9 %).
 // frame_width = 0: accum / counts are the region's own [h][w] buffers; otherwise they are full frames of that
 // width and pixel (x, y) of the image is element y * frame_width + x.
-__global__ __launch_bounds__(256) void accumulate_kernel(const float *out, uint32_t npix, uint32_t spp, float *accum,
+enum { ACC_TILE = 16, ACC_ROW = 3 * ACC_TILE + 1 };       // + 1 word: rows 49 words apart, no bank conflicts
+__global__ __launch_bounds__(256) void accumulate_kernel(const float *__restrict__ out, uint32_t npix, uint32_t spp, float *accum,
                                                          uint32_t *counts, RenderArgs ra, int frame_width) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
+    __shared__ float s_tile[256 * ACC_ROW];
+    const uint32_t p0 = blockIdx.x * 256u, p = p0 + threadIdx.x;
+    const uint32_t np = min(256u, npix - p0);                          // pixels of this workgroup
+    const bool live = p < npix;
     size_t q = p;
-    if (frame_width > 0) {
-        int x, y;
-        region_pixel(ra, p, x, y);
-        q = (size_t)y * (size_t)frame_width + (size_t)x;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    if (live) {
+        if (frame_width > 0) {
+            int x, y;
+            region_pixel(ra, p, x, y);
+            q = (size_t)y * (size_t)frame_width + (size_t)x;
+        }
+        r = accum[3 * q]; g = accum[3 * q + 1]; b = accum[3 * q + 2];
     }
-    float r = accum[3 * q], g = accum[3 * q + 1], b = accum[3 * q + 2];
-    const float *o = out + 3 * (size_t)p * spp;
-    for (uint32_t s = 0; s < spp; ++s) { r += o[3 * s]; g += o[3 * s + 1]; b += o[3 * s + 2]; }
-    accum[3 * q] = r; accum[3 * q + 1] = g; accum[3 * q + 2] = b;
-    counts[q] += spp;
+    const float *base = out + 3 * (size_t)p0 * spp;
+    for (uint32_t s0 = 0; s0 < spp; s0 += ACC_TILE) {
+        const uint32_t ns = min((uint32_t)ACC_TILE, spp - s0), row = 3 * ns;      // floats per pixel in this tile
+        for (uint32_t j = threadIdx.x; j < np * row; j += 256) {
+            const uint32_t px = j / row, k = j - px * row;
+            s_tile[px * ACC_ROW + k] = base[(size_t)px * spp * 3 + (size_t)s0 * 3 + k];
+        }
+        __syncthreads();
+        if (live) {
+            const float *t = s_tile + threadIdx.x * ACC_ROW;
+            for (uint32_t s = 0; s < ns; ++s) { r += t[3 * s]; g += t[3 * s + 1]; b += t[3 * s + 2]; }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        accum[3 * q] = r; accum[3 * q + 1] = g; accum[3 * q + 2] = b;
+        counts[q] += spp;
+    }
 }
 
 }  // namespace
