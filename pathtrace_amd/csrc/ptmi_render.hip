@@ -492,6 +492,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     V3 out_o = mk(0, 0, 0), out_d = mk(0, 0, 0);   // the ray of a path that wants an extend (goes into its queue entry)
     float4 out_a0 = make_float4(0, 0, 0, 0), out_a1 = out_a0, out_a2 = out_a0;   // ... and its pending-call state
     V3 sh_o = mk(0, 0, 0), sh_eo = mk(0, 0, 0);    // origins of the staged shadow rays (sky / light rays; emissive sample)
+    float4 *store_to = nullptr;                    // where the top frame (still in LDS) is parked when the path leaves
     if (live) {
         const bool pending = i < na;                                        // the extend list holds exactly the pending calls
         float4 qa = make_float4(0, 0, 0, 0), qb = qa, a0, a1 = qa, a2, hq = qa;
@@ -556,10 +557,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const float4 v = f[k]; FW(4 * k) = v.x; FW(4 * k + 1) = v.y; FW(4 * k + 2) = v.z; if (4 * k + 3 < FRW) FW(4 * k + 3) = v.w; }
         };
+        // A frame is parked (under a child, or to wait for its shadow rays) only as the LAST thing a visit does, so the
+        // store is deferred to the end of the kernel, where the whole wave writes the parked frames together: 8 lanes per
+        // 128-byte line (one lane storing its own line takes eight instructions that each touch 16 bytes of 64 lines).
         auto store_frame = [&](int dep) {
+#if PTMI_FRAME_REGS
             float4 *f = frames + (size_t)dep * 8;
 #pragma unroll
             for (int k = 0; k < 8; ++k) f[k] = make_float4(FW(4 * k), FW(4 * k + 1), FW(4 * k + 2), 4 * k + 3 < FRW ? FW(4 * k + 3) : 0.0f);
+#else
+            store_to = frames + (size_t)dep * 8;
+#endif
         };
 #define FV(field) mk(FW(field), FW((field) + 1), FW((field) + 2))
 #define FV_SET(field, v) do { V3 v__ = (v); FW(field) = v__.x; FW((field) + 1) = v__.y; FW((field) + 2) = v__.z; } while (0)
@@ -891,7 +899,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         if (err && !finished) {
             atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)err);
-            want_extend = want_shadow = false; n_sray = 0; need_out = 0; finished = true;
+            want_extend = want_shadow = false; n_sray = 0; need_out = 0; finished = true; store_to = nullptr;
         }
         if (!finished) {      // the state that travels with the path, for its next queue entry
             out_a0 = make_float4(a0.x, a0.y, u2f(rng.ctr), u2f((uint32_t)depth | trk_len << 8));
@@ -909,6 +917,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #undef FU
 #undef FI_SET
 #undef FU_SET
+    }
+    // ---- parked frames: the wave stores them together, lane 8 g + j writing quarter-line j of the frames of lanes
+    // 8 g .. 8 g + 7 in turn (the frames are still in this wave's LDS columns; the compaction below reuses them) ----
+    {
+        const unsigned long long m_st = __ballot(store_to != nullptr);
+        if (m_st) {
+            const int lane = threadIdx.x & 63, grp = lane & ~7, sub = lane & 7;
+            const uint32_t lo = (uint32_t)(uintptr_t)store_to, hi = (uint32_t)((uintptr_t)store_to >> 32);
+            for (int i = 0; i < 8; ++i) {
+                const int src = grp + i;
+                const uint32_t slo = (uint32_t)__shfl((int)lo, src), shi = (uint32_t)__shfl((int)hi, src);
+                if (m_st >> src & 1ull) {
+                    float4 *dst = (float4 *)(((uintptr_t)shi << 32) | (uintptr_t)slo);
+                    const float *col = s_fw + (threadIdx.x & ~63u) + (uint32_t)src;
+                    dst[sub] = make_float4(col[(4 * sub) * 256], col[(4 * sub + 1) * 256], col[(4 * sub + 2) * 256],
+                                           4 * sub + 3 < FRW ? col[(4 * sub + 3) * 256] : 0.0f);
+                }
+            }
+        }
     }
     // ---- queue compaction: one atomic per workgroup and queue (ballot + popcount per wave, 4 waves summed in LDS) ----
     {
