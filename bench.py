@@ -219,8 +219,9 @@ def roofline_block(wl, c, alg_bytes, kernel_ms, traffic, note):
 
 
 def stack_class(depth):
-    for s in (16, 24, 32, 48):
-        if depth <= s:
+    """Stack size of the kernel instantiation a tree of this depth runs (ptmi_ctx::stack_entries: depth - 1 entries)."""
+    for s in (16, 20, 24, 28, 32, 48):
+        if depth - 1 <= s:
             return s
     return 64
 

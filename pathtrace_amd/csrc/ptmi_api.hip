@@ -489,10 +489,12 @@ extern "C" int ptmi_bvh_stats(ptmi_ctx *ctx, PtBvhStats *out) {
 static int dispatch_extend(ptmi_ctx *ctx, const LaunchScratch &sc, const float *o, const float *d, const float *tmax, uint64_t n,
                            int32_t *prim, float *t, hipStream_t s) {
     if (n > PTMI_MAX_RAYS_PER_CALL) return set_err(ctx, PTMI_ERR_INVALID, "too many rays in one call");
-    const int dep = ctx->max_depth;
+    const int dep = ctx->stack_entries();
     int rc;
     if (dep <= 16) rc = launch_extend<16>(ctx, sc, o, d, tmax, n, prim, t, s);
+    else if (dep <= 20) rc = launch_extend<20>(ctx, sc, o, d, tmax, n, prim, t, s);
     else if (dep <= 24) rc = launch_extend<24>(ctx, sc, o, d, tmax, n, prim, t, s);
+    else if (dep <= 28) rc = launch_extend<28>(ctx, sc, o, d, tmax, n, prim, t, s);      // 1-8 M-triangle trees: 22 waves per CU instead of 20
     else if (dep <= 32) rc = launch_extend<32>(ctx, sc, o, d, tmax, n, prim, t, s);
     else if (dep <= 48) rc = launch_extend<48>(ctx, sc, o, d, tmax, n, prim, t, s);
     else rc = launch_extend<64>(ctx, sc, o, d, tmax, n, prim, t, s);
@@ -503,10 +505,12 @@ static int dispatch_extend(ptmi_ctx *ctx, const LaunchScratch &sc, const float *
 static int dispatch_connect(ptmi_ctx *ctx, const LaunchScratch &sc, const float *o, const float *d, const float *tmax, uint64_t n,
                             uint8_t *occ, hipStream_t s) {
     if (n > PTMI_MAX_RAYS_PER_CALL) return set_err(ctx, PTMI_ERR_INVALID, "too many rays in one call");
-    const int dep = ctx->max_depth;
+    const int dep = ctx->stack_entries();
     int rc;
     if (dep <= 16) rc = launch_connect<16>(ctx, sc, o, d, tmax, n, occ, s);
+    else if (dep <= 20) rc = launch_connect<20>(ctx, sc, o, d, tmax, n, occ, s);
     else if (dep <= 24) rc = launch_connect<24>(ctx, sc, o, d, tmax, n, occ, s);
+    else if (dep <= 28) rc = launch_connect<28>(ctx, sc, o, d, tmax, n, occ, s);
     else if (dep <= 32) rc = launch_connect<32>(ctx, sc, o, d, tmax, n, occ, s);
     else if (dep <= 48) rc = launch_connect<48>(ctx, sc, o, d, tmax, n, occ, s);
     else rc = launch_connect<64>(ctx, sc, o, d, tmax, n, occ, s);

@@ -43,6 +43,12 @@ struct ptmi_ctx {
     double build_ms = 0.0;
     uint64_t packed_inner = 0, packed_tris = 0;
     int max_depth = 0;
+    // Entries the traversal stack needs.  max_depth counts the root as 1 (GetStats(1), main.go:809), so a leaf at the
+    // deepest level has max_depth - 1 inner ancestors; a walk defers at most one child per inner node on its current
+    // path, and an entry pushed at a deeper level is popped before one from a shallower level, so the entries in use
+    // always belong to distinct levels: max_depth - 1 at most.  (The kernels come in stack sizes 16 / 20 / 24 / 28 / 32 /
+    // 48 / 64; the LDS stack is what bounds the resident waves: 32 per CU with 20 entries, 26 with 24, 22 with 28, 20 with 32.)
+    int stack_entries() const { return max_depth > 1 ? max_depth - 1 : 1; }
     float4 *d_nodes = nullptr;
     float4 *d_tris = nullptr;
     uint32_t root_ref = ptmi::D_REF_EMPTY_LEAF;

@@ -1410,9 +1410,11 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
 }
 static int enqueue_iteration(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, uint64_t lane_total, int cur,
                              hipStream_t s) {
-    const int dep = ctx->max_depth;      // the LDS stack is as deep as the tree
+    const int dep = ctx->stack_entries();
     if (dep <= 16) return enqueue_iteration_t<16>(ctx, pl, sc, ra, lane_total, cur, s);
+    if (dep <= 20) return enqueue_iteration_t<20>(ctx, pl, sc, ra, lane_total, cur, s);
     if (dep <= 24) return enqueue_iteration_t<24>(ctx, pl, sc, ra, lane_total, cur, s);
+    if (dep <= 28) return enqueue_iteration_t<28>(ctx, pl, sc, ra, lane_total, cur, s);
     if (dep <= 32) return enqueue_iteration_t<32>(ctx, pl, sc, ra, lane_total, cur, s);
     if (dep <= 48) return enqueue_iteration_t<48>(ctx, pl, sc, ra, lane_total, cur, s);
     return enqueue_iteration_t<64>(ctx, pl, sc, ra, lane_total, cur, s);

@@ -258,3 +258,68 @@ def test_host_batches_from_page_locked_buffers_go_through_in_chunks(gpu_ctx):
     orc = oracle_lib.OracleBVH(v, f, linear=box.linear())
     op, ot, _ = orc.closest_hit(np.ascontiguousarray(o[idx]), np.ascontiguousarray(d[idx]), np.ascontiguousarray(tmax[idx]))
     assert np.array_equal(P.numpy()[idx], op) and bits_equal(Tt.numpy()[idx], ot)
+
+
+def _caterpillar(depth):
+    """A tree in the reference's LinearBVH form whose every inner node has an inner child and a one-triangle leaf child:
+    max depth `depth` (root = 1), and a ray along +z through all of it defers one leaf per level, so the traversal stack
+    holds depth - 1 entries -- the most a tree of that depth can ask for."""
+    from pathtrace_amd.api import LinearArrays
+    D = depth
+    ntri = D                                              # leaf_k for k = 0 .. D-2, and the bottom leaf
+    # triangle k (k = 0 .. D-2) sits at z = k + 1, the bottom triangle (number D-1) at z = 0; all cross the z axis
+    v = np.zeros((3 * ntri, 3), np.float32)
+    for k in range(ntri):
+        z = float(k + 1) if k < D - 1 else 0.0
+        v[3 * k:3 * k + 3] = [[-2.0, -2.0, z], [2.0, -2.0, z], [0.0, 3.0, z]]
+    f = np.arange(3 * ntri, dtype=np.uint32).reshape(-1, 3)
+    nn = 2 * D - 1
+    bounds = np.zeros((nn, 6), np.float32)
+    is_leaf = np.zeros(nn, np.uint8); off = np.zeros(nn, np.uint32); cnt = np.zeros(nn, np.uint32); second = np.zeros(nn, np.uint32)
+    tri_ids = np.zeros(ntri, np.uint32)
+
+    def tri_box(k):
+        p = v[3 * k:3 * k + 3]
+        return np.concatenate([p.min(0), p.max(0)])
+    # pre-order: inner 0 .. D-2, the bottom leaf, then leaf D-2 .. leaf 0
+    leaf_index = {k: 2 * D - 2 - k for k in range(D - 1)}
+    bottom = D - 1
+    order = [D - 1] + list(range(D - 2, -1, -1))          # triangles in leaf (pre-order) order
+    for pos, k in enumerate(order):
+        tri_ids[pos] = k
+        node = bottom if k == D - 1 else leaf_index[k]
+        is_leaf[node] = 1; off[node] = pos; cnt[node] = 1; bounds[node] = tri_box(k)
+    for k in range(D - 2, -1, -1):                         # inner k = its first child (k + 1: inner or bottom leaf) + leaf k
+        a, b = bounds[k + 1], bounds[leaf_index[k]]
+        bounds[k] = np.concatenate([np.minimum(a[:3], b[:3]), np.maximum(a[3:], b[3:])])
+        second[k] = leaf_index[k]
+    return v, f, LinearArrays(bounds, is_leaf, off, cnt, second, tri_ids)
+
+
+@pytest.mark.parametrize("depth", [2, 17, 18, 21, 25, 29, 33, 49])
+def test_deepest_stack_a_tree_can_ask_for(gpu_ctx, depth, monkeypatch):
+    """The kernels' LDS stacks are sized by the tree: depth - 1 entries (ptmi_ctx::stack_entries), in classes of 16 / 20 /
+    24 / 28 / 32 / 48 / 64.  Depths 17, 21, 25, 29, 33 and 49 fill their class to the last entry with rays that defer a child at
+    every level; closest hit and any hit equal the oracle on them and on random rays, for the vote-scheduled and the
+    one-shot kernels."""
+    from pathtrace_amd import UploadLinearBVH, Context
+    v, f, arrays = _caterpillar(depth)
+    orc = oracle_lib.OracleBVH(v, f, linear=arrays)
+    n = 4096
+    rng = np.random.default_rng(depth)
+    o = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.5, 1.5, n), np.full(n, -5.0)], 1).astype(np.float32)
+    d = np.tile(np.array([0.0, 0.0, 1.0], np.float32), (n, 1))
+    d[n // 2:] = [0.0, 0.0, -1.0]; o[n // 2:, 2] = depth + 5.0                 # and from the other end
+    d[::5] += rng.uniform(-0.05, 0.05, (len(d[::5]), 3)).astype(np.float32)    # slightly off axis
+    o2, d2 = random_rays(v, n, depth + 1)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    bvh = UploadLinearBVH(v, f, arrays, ctx=gpu_ctx)
+    assert bvh.GetStats().max_depth == depth
+    hit = _check(bvh, orc, o, d, 1000.0, f"caterpillar{depth}/vote")
+    assert hit[:n].mean() > 0.5
+    monkeypatch.setenv("PTMI_EXTEND_VARIANT", "0")
+    ctx = Context(0)
+    try:
+        _check(UploadLinearBVH(v, f, arrays, ctx=ctx), orc, o, d, 1000.0, f"caterpillar{depth}/one-shot")
+    finally:
+        ctx.close()
