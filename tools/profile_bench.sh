@@ -26,6 +26,6 @@ run pmc_sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE
 run pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_LEVEL_WAVES TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum || exit 1
 run pmc_mem --pmc TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum || exit 1
 python3 tools/summarize_pmc.py "$OUT" "extend_vote_kernel<24, false>" > "$OUT/pmc_summary.txt" 2>&1
-python3 tools/summarize_pmc.py "$OUT" "extend_vote_kernel<32, false>" > "$OUT/pmc_summary_hbm_leg.txt" 2>&1
+python3 tools/summarize_pmc.py "$OUT" "extend_vote_kernel<28, false>" > "$OUT/pmc_summary_hbm_leg.txt" 2>&1
 cp "$OUT"/kt/*/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null
 echo done
