@@ -607,7 +607,7 @@ def main():
         wl2 = build_workload(args.hbm_tris, args.rays, args.tmax, rank, torch, dev, "HBM-resident leg")
         wl2["stack"] = stack_class(int(wl2["stats"].max_depth))
         c2, alg2 = count_work(wl2, stream)
-        wall2, kms2 = time_extend(wl2, max(3, args.steps // 2), 1, torch, None, stream)
+        wall2, kms2 = time_extend(wl2, max(3, args.steps // 2), 2, torch, None, stream)
         steps2 = max(3, args.steps // 2)
         rb = roofline_block(wl2, c2, alg2, kms2, traffic[1] if traffic and len(traffic) > 1 else None,
                             "HBM-resident leg: the packed tree exceeds the 256 MiB Infinity Cache; the hot top of the tree is "
