@@ -139,8 +139,30 @@ __global__ __launch_bounds__(WAVE) void connect_vote_kernel(DevBVH bvh, const fl
 }
 
 // Where a launch keeps its device-side scratch: the work counters (CNT_SHARDS lines) and this launch's ray cursor.
-struct LaunchScratch { unsigned long long *counters, *cursor; };
-static LaunchScratch ctx_scratch(ptmi_ctx *ctx) { return LaunchScratch{ctx->d_counters, ctx->next_cursor()}; }
+struct LaunchScratch { unsigned long long *counters, *cursor; int line; };
+// The next line of the context's cursor ring.  A line whose previous launch (64 launches ago) has not finished yet is
+// waited for: the ring then never hands a live kernel's cursor to a second launch.  Streams under capture record and
+// wait for nothing (an event recorded into a graph cannot be waited for from outside it; the capturing caller orders
+// its launches itself, as ptmi_closest_hit_dev_noalloc's contract says).
+static int ctx_scratch(ptmi_ctx *ctx, LaunchScratch &out) {
+    const int line = (int)(ctx->cursor_seq++ % CNT_CURSOR_LINES);
+    if (ctx->cursor_pending[line]) {
+        PTMI_HIP(ctx, hipEventSynchronize(ctx->cursor_ev[line]));
+        ctx->cursor_pending[line] = false;
+    }
+    out = LaunchScratch{ctx->d_counters, ctx->d_counters + CNT_CURSOR + (size_t)line * CNT_WORDS, line};
+    return PTMI_OK;
+}
+static int scratch_launched(ptmi_ctx *ctx, const LaunchScratch &sc, hipStream_t s) {
+    if (sc.line < 0) return PTMI_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return PTMI_OK; }
+    if (cap != hipStreamCaptureStatusNone) return PTMI_OK;
+    if (!ctx->cursor_ev[sc.line]) PTMI_HIP(ctx, hipEventCreateWithFlags(&ctx->cursor_ev[sc.line], hipEventDisableTiming));
+    PTMI_HIP(ctx, hipEventRecord(ctx->cursor_ev[sc.line], s));
+    ctx->cursor_pending[sc.line] = true;
+    return PTMI_OK;
+}
 
 template <int STACK>
 static int launch_extend(ptmi_ctx *ctx, const LaunchScratch &sc, const float *o, const float *d, const float *tmax, uint64_t n,
@@ -188,6 +210,26 @@ static int launch_connect(ptmi_ctx *ctx, const LaunchScratch &sc, const float *o
         hipLaunchKernelGGL((connect_vote_kernel<STACK, false>), pgrid, block, 0, s, ctx->dev_bvh(), o, d, tmax, n, occ,
                            sc.counters, sc.cursor, ctx->vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->vote_chunk);
     return PTMI_OK;
+}
+
+// Resident waves per CU of the persistent batch kernels of one stack class, asked for once per context when a tree is
+// uploaded (the class follows from the tree's depth): a query call can load a code object, which a caller under
+// stream capture -- ptmi_closest_hit_dev_noalloc's audience -- must not trigger, so no batch call makes one.
+template <int STACK>
+static void resolve_occupancy_t(ptmi_ctx *ctx) {
+    for (const void *fn : {(const void *)extend_vote_kernel<STACK, false>, (const void *)extend_vote_kernel<STACK, true>,
+                           (const void *)connect_vote_kernel<STACK, false>, (const void *)connect_vote_kernel<STACK, true>})
+        (void)ctx->waves_per_cu(fn, WAVE);
+}
+static void resolve_occupancy(ptmi_ctx *ctx) {
+    const int dep = ctx->stack_entries();
+    if (dep <= 16) resolve_occupancy_t<16>(ctx);
+    else if (dep <= 20) resolve_occupancy_t<20>(ctx);
+    else if (dep <= 24) resolve_occupancy_t<24>(ctx);
+    else if (dep <= 28) resolve_occupancy_t<28>(ctx);
+    else if (dep <= 32) resolve_occupancy_t<32>(ctx);
+    else if (dep <= 48) resolve_occupancy_t<48>(ctx);
+    else resolve_occupancy_t<64>(ctx);
 }
 
 // ------------------------------------------------------------------------------------ allocation-free scratch
@@ -286,6 +328,7 @@ extern "C" void ptmi_destroy(ptmi_ctx *ctx) {
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (auto &sp : ctx->prof_open) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->cursor_ev) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -337,6 +380,7 @@ static int upload_packed(ptmi_ctx *ctx, LinearBVH &lin, const float *verts, uint
     ctx->verts.assign(verts, verts + 3 * nverts);
     ctx->tri_idx.assign(tri_idx, tri_idx + 3 * ntris);
     ctx->have_bvh = true;
+    resolve_occupancy(ctx);
     return PTMI_OK;
 }
 
@@ -526,7 +570,11 @@ extern "C" int ptmi_closest_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const flo
     if (n == 0) return PTMI_OK;
     if (!o_xyz || !d_xyz || !tmax || !prim_id || !t) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_closest_hit_dev: null buffer");
     PTMI_HIP(ctx, hipSetDevice(ctx->device));
-    return dispatch_extend(ctx, ctx_scratch(ctx), o_xyz, d_xyz, tmax, n, prim_id, t, (hipStream_t)stream);
+    LaunchScratch sc;
+    int rc = ctx_scratch(ctx, sc);
+    if (rc) return rc;
+    if ((rc = dispatch_extend(ctx, sc, o_xyz, d_xyz, tmax, n, prim_id, t, (hipStream_t)stream))) return rc;
+    return scratch_launched(ctx, sc, (hipStream_t)stream);
 }
 
 // Allocation-free form of ptmi_closest_hit_dev: the same kernels, the ray cursor in the static scratch array.  Calls no
@@ -548,7 +596,7 @@ extern "C" int ptmi_closest_hit_dev_noalloc(ptmi_ctx *ctx, const float *o_xyz, c
     PTMI_HIP(ctx, hipMemsetAsync(ctx->noalloc_scratch, 0, NOALLOC_SCRATCH_BYTES, s));
     // work counting selects kernels that add to the context's hipMalloc'd counter block, which is still valid memory
     // here (allocated at ptmi_create); only the cursor moves into the scratch
-    const LaunchScratch sc{ctx->d_counters, ctx->noalloc_scratch};
+    const LaunchScratch sc{ctx->d_counters, ctx->noalloc_scratch, -1};
     return dispatch_extend(ctx, sc, o_xyz, d_xyz, tmax, n, prim_id, t, s);
 }
 
@@ -559,7 +607,11 @@ extern "C" int ptmi_any_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const float *
     if (n == 0) return PTMI_OK;
     if (!o_xyz || !d_xyz || !tmax || !occluded) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_any_hit_dev: null buffer");
     PTMI_HIP(ctx, hipSetDevice(ctx->device));
-    return dispatch_connect(ctx, ctx_scratch(ctx), o_xyz, d_xyz, tmax, n, occluded, (hipStream_t)stream);
+    LaunchScratch sc;
+    int rc = ctx_scratch(ctx, sc);
+    if (rc) return rc;
+    if ((rc = dispatch_connect(ctx, sc, o_xyz, d_xyz, tmax, n, occluded, (hipStream_t)stream))) return rc;
+    return scratch_launched(ctx, sc, (hipStream_t)stream);
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -572,11 +624,12 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 constexpr uint64_t HOST_CHUNK_RAYS = 1ull << 21;
 
 template <typename Launch, typename CopyOut>
-static int host_batch(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n, size_t out_bytes_per_ray,
+static int host_batch(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, const float *tmax, uint64_t n, size_t out_bytes,
                       Launch launch, CopyOut copy_out) {
     PTMI_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->stream2) PTMI_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    const size_t b3 = align_up(n * 12, 256), b1 = align_up(n * 4, 256), bo = align_up(n * out_bytes_per_ray, 256);
+    // out_bytes: what the caller's layout of the staged answers takes in all (its own alignment padding included)
+    const size_t b3 = align_up(n * 12, 256), b1 = align_up(n * 4, 256), bo = align_up(out_bytes, 256);
     int rc = ensure_stage(ctx, 2 * b3 + b1 + bo);
     if (rc) return rc;
     char *base = (char *)ctx->d_stage;
@@ -613,11 +666,15 @@ extern "C" int ptmi_closest_hit(ptmi_ctx *ctx, const float *o_xyz, const float *
     if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_closest_hit: no BVH uploaded");
     if (n == 0) return PTMI_OK;
     if (!o_xyz || !d_xyz || !tmax || !prim_id || !t) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_closest_hit: null buffer");
-    const size_t half = align_up(n * 4, 256);          // staged answers: prim ids, then t
+    const size_t half = align_up(n * 4, 256);          // staged answers: prim ids, then t (each padded to 256 bytes)
     return host_batch(
-        ctx, o_xyz, d_xyz, tmax, n, 8,
+        ctx, o_xyz, d_xyz, tmax, n, 2 * half,
         [&](const float *dO, const float *dD, const float *dT, uint64_t m, char *dOut, uint64_t first, hipStream_t s) {
-            return dispatch_extend(ctx, ctx_scratch(ctx), dO, dD, dT, m, (int32_t *)dOut + first, (float *)(dOut + half) + first, s);
+            LaunchScratch sc;
+            int r = ctx_scratch(ctx, sc);
+            if (r) return r;
+            if ((r = dispatch_extend(ctx, sc, dO, dD, dT, m, (int32_t *)dOut + first, (float *)(dOut + half) + first, s))) return r;
+            return scratch_launched(ctx, sc, s);
         },
         [&](char *dOut, uint64_t first, uint64_t m, hipStream_t s) -> int {
             PTMI_HIP(ctx, hipMemcpyAsync(prim_id + first, (int32_t *)dOut + first, m * 4, hipMemcpyDeviceToHost, s));
@@ -633,9 +690,13 @@ extern "C" int ptmi_any_hit(ptmi_ctx *ctx, const float *o_xyz, const float *d_xy
     if (n == 0) return PTMI_OK;
     if (!o_xyz || !d_xyz || !tmax || !occluded) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_any_hit: null buffer");
     return host_batch(
-        ctx, o_xyz, d_xyz, tmax, n, 1,
+        ctx, o_xyz, d_xyz, tmax, n, n,
         [&](const float *dO, const float *dD, const float *dT, uint64_t m, char *dOut, uint64_t first, hipStream_t s) {
-            return dispatch_connect(ctx, ctx_scratch(ctx), dO, dD, dT, m, (uint8_t *)dOut + first, s);
+            LaunchScratch sc;
+            int r = ctx_scratch(ctx, sc);
+            if (r) return r;
+            if ((r = dispatch_connect(ctx, sc, dO, dD, dT, m, (uint8_t *)dOut + first, s))) return r;
+            return scratch_launched(ctx, sc, s);
         },
         [&](char *dOut, uint64_t first, uint64_t m, hipStream_t s) -> int {
             PTMI_HIP(ctx, hipMemcpyAsync(occluded + first, (uint8_t *)dOut + first, m, hipMemcpyDeviceToHost, s));

@@ -142,14 +142,27 @@ extern "C" int ptmi_comm_init_all(ptmi_ctx **ctxs, int n) {
     PTMI_NCCL(ctxs[0], g_rccl.GetUniqueId(&u));
     for (int i = 0; i < n; ++i) ptmi_comm_destroy(ctxs[i]);
     std::vector<ncclComm_t> comms((size_t)n, nullptr);
-    PTMI_NCCL(ctxs[0], g_rccl.GroupStart());
+    int dev_before = -1;
+    (void)hipGetDevice(&dev_before);
+    // On any failure after GroupStart the group is closed, every communicator it did create is destroyed and the caller's
+    // device is current again: the contexts are left without communicators (worlds of one), never half-initialised.
+    auto fail = [&](ptmi_ctx *at, ncclResult_t e, const char *what, bool group_open) {
+        if (group_open) (void)g_rccl.GroupEnd();
+        for (ncclComm_t c : comms) if (c) (void)g_rccl.CommDestroy(c);
+        if (dev_before >= 0) (void)hipSetDevice(dev_before);
+        return nccl_err(at, e, what);
+    };
+    ncclResult_t e = g_rccl.GroupStart();
+    if (e != ncclSuccess) return fail(ctxs[0], e, "ncclGroupStart", false);
     for (int i = 0; i < n; ++i) {
         hipError_t he = hipSetDevice(ctxs[i]->device);
-        ncclResult_t e = he == hipSuccess ? g_rccl.CommInitRank(&comms[(size_t)i], n, u, i) : ncclUnhandledCudaError;
-        if (e != ncclSuccess) { (void)g_rccl.GroupEnd(); return nccl_err(ctxs[i], e, "ncclCommInitRank"); }
+        e = he == hipSuccess ? g_rccl.CommInitRank(&comms[(size_t)i], n, u, i) : ncclUnhandledCudaError;
+        if (e != ncclSuccess) return fail(ctxs[i], e, "ncclCommInitRank", true);
     }
-    PTMI_NCCL(ctxs[0], g_rccl.GroupEnd());
+    e = g_rccl.GroupEnd();
+    if (e != ncclSuccess) return fail(ctxs[0], e, "ncclGroupEnd", false);
     for (int i = 0; i < n; ++i) { ctxs[i]->comm = comms[(size_t)i]; ctxs[i]->comm_rank = i; ctxs[i]->comm_nranks = n; }
+    if (dev_before >= 0) (void)hipSetDevice(dev_before);
     return PTMI_OK;
 }
 
@@ -194,18 +207,22 @@ extern "C" int ptmi_render_sharded(ptmi_ctx *ctx, const PtCamera *camera, const 
     if (params->width <= 0 || params->height <= 0) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_sharded: empty image");
     if (root < 0 || root >= ctx->comm_nranks) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_sharded: root out of range");
     const size_t npix = (size_t)params->width * (size_t)params->height;
-    PTMI_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
+    // From here on every path leads through the reduce: the other ranks are already on their way into it and would
+    // wait for ever for a rank that left early.  The first error (set-device, the clears, the render) is kept and
+    // returned after the reduce; the failing rank joins with whatever its buffers hold and the frame is not valid.
+    int rc = PTMI_OK;
+    std::string first_err;
+    auto note = [&](int r) { if (r && !rc) { rc = r; first_err = ctx->err; } };
+    auto hip = [&](hipError_t e, const char *what) { if (e != hipSuccess) note(ptmi::hip_err(ctx, e, what)); };
+    hip(hipSetDevice(ctx->device), "hipSetDevice");
     // every rank's frame starts at zero: its own rows get this call's samples, the others stay 0 for the sum
-    PTMI_HIP(ctx, hipMemsetAsync(accum_rgb, 0, npix * 12, s));
-    PTMI_HIP(ctx, hipMemsetAsync(counts, 0, npix * 4, s));
-    int rc = ptmi_render_rows_dev(ctx, camera, params, row_block, ctx->comm_rank, ctx->comm_nranks, spp_begin, spp_count, accum_rgb,
-                                  counts, stream);
+    if (!rc) hip(hipMemsetAsync(accum_rgb, 0, npix * 12, s), "hipMemsetAsync(accum)");
+    if (!rc) hip(hipMemsetAsync(counts, 0, npix * 4, s), "hipMemsetAsync(counts)");
+    if (!rc) note(ptmi_render_rows_dev(ctx, camera, params, row_block, ctx->comm_rank, ctx->comm_nranks, spp_begin, spp_count,
+                                       accum_rgb, counts, stream));
     if (ctx->comm_nranks == 1) return rc;
-    // A rank whose render failed still takes part in the reduce (with whatever its buffers hold): the other ranks are
-    // already on their way into it and would wait for ever.  The failing rank reports its error; the frame is not valid.
-    std::string render_err = rc ? ctx->err : std::string();
     int rr = ptmi_reduce_frame(ctx, accum_rgb, counts, accum_rgb, counts, params->width, params->height, root, stream);
-    if (rc) { ctx->err = render_err; return rc; }
+    if (rc) { ctx->err = first_err; return rc; }
     return rr;
 }

@@ -97,7 +97,10 @@ struct ptmi_ctx {
     bool counting = false;
     unsigned long long *d_counters = nullptr;
     uint32_t cursor_seq = 0;            // next line of the cursor ring (calls on one ctx are serialised by the caller)
-    unsigned long long *next_cursor() { return d_counters + CNT_CURSOR + (size_t)(cursor_seq++ % CNT_CURSOR_LINES) * CNT_WORDS; }
+    // One event per line of the ring, recorded behind the launch that uses the line: the 65th launch in flight waits for
+    // the line's previous user instead of sharing (and re-zeroing) a live kernel's cursor (ptmi_api.hip: ctx_scratch).
+    hipEvent_t cursor_ev[CNT_CURSOR_LINES] = {};
+    bool cursor_pending[CNT_CURSOR_LINES] = {};
     // resident workgroups per CU of the persistent kernels, per kernel function (per context: contexts may be driven
     // from different OS threads, and different devices may answer differently)
     std::unordered_map<const void *, int> occupancy;

@@ -1452,6 +1452,19 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     // the per-sample output is laid out [pixel][sample] over the WHOLE sample range, which only one pass produces
     // (ptmi_render_samples caps a call at 2^28 samples, so the buffer stays bounded)
     if (out_samples_host) spp_chunk = spp_count;
+    // The per-sample output buffer first (12 bytes per sample of a pass); when device memory is short the pass is
+    // halved until it fits (more passes, same sums: accumulate adds them in sample order), PTMI_ERR_OOM when even one
+    // sample per pixel does not -- or for ptmi_render_samples, whose layout needs the whole range in one pass.
+    while (rs->out_bytes < npix * spp_chunk * 12) {
+        if (rs->d_out) { (void)hipFree(rs->d_out); rs->d_out = nullptr; rs->out_bytes = 0; }
+        if (hipMalloc((void **)&rs->d_out, npix * spp_chunk * 12) == hipSuccess) { rs->out_bytes = npix * spp_chunk * 12; break; }
+        (void)hipGetLastError();
+        rs->d_out = nullptr;
+        if (out_samples_host || spp_chunk == 1)
+            return set_err(ctx, PTMI_ERR_OOM, "ptmi_render: out of device memory for the per-sample output buffer (" +
+                                              std::to_string(npix * spp_chunk * 12) + " bytes)");
+        spp_chunk = (spp_chunk + 1) / 2;
+    }
     const uint64_t max_total = npix * spp_chunk;
     // Every wavefront iteration costs time that does not depend on the number of paths (the tails of three kernels
     // that wait for their longest rays), so the pool is as large as the work and the memory budget allow: 2 M paths
@@ -1471,12 +1484,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     const int lanes = (want_lanes >= 2 && max_total >= (1ull << 22) && !ctx->profiling) ? std::min(want_lanes, (int)RenderState::MAX_LANES) : 1;
     uint32_t cap = (uint32_t)std::min<uint64_t>({(max_total + lanes - 1) / lanes, (uint64_t)ctx->pool_paths / lanes, by_budget / lanes});
     cap = (cap + 255) / 256 * 256;
-    // the per-sample output buffer first (its size is fixed by the request), then as large a pool as fits
-    if (rs->out_bytes < max_total * 12) {
-        if (rs->d_out) { (void)hipFree(rs->d_out); rs->d_out = nullptr; rs->out_bytes = 0; }
-        PTMI_HIP(ctx, hipMalloc((void **)&rs->d_out, max_total * 12));
-        rs->out_bytes = max_total * 12;
-    }
+    // the per-sample output buffer is in place (above); now as large a pool as fits
     int rc;
     while ((rc = ensure_pool(ctx, cap, bounces, lanes)) == PTMI_ERR_OOM && cap > (1u << 16))
         cap = (cap / 2 + 255) / 256 * 256;          // device memory is short (other contexts on this GPU): halve

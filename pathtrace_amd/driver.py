@@ -114,6 +114,21 @@ class Stats:
                 f"({100.0 * samples / self.total:.1f}%)  {int(el) // 60:02d}:{int(el) % 60:02d} / {rem // 60:02d}:{rem % 60:02d}")
 
 
+def checkpoint_tag(scene, params, cam, spp, splits):
+    """What a checkpoint must agree on to be continued: image size, integrator parameters, seed, spp, tiling, camera and
+    the scene's geometry and materials (a hash, as hex)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(repr((params.width, params.height, params.bounces, params.scatter_rays, params.max_steps, float(params.ambient),
+                   float(params.step_size), params.seed, int(spp), tuple(splits))).encode())
+    h.update(np.asarray(cam.as_array(), np.float32).tobytes())
+    for name in ("verts", "tris", "normals", "materials", "tri_material", "lights", "sky"):
+        v = getattr(scene, name, None)
+        if v is not None:
+            h.update(np.ascontiguousarray(v).tobytes())
+    return h.hexdigest()[:32]
+
+
 def frame_loop(renderer, scene, params, frames=1, spp=32, splits=(4, 4), out_dir=None, orbit=None, log=print,
                checkpoint=None):
     """main.go:454-491 tiles, :832-899 per-tile work, :904-939 write the frame / orbit / restart.
@@ -129,11 +144,20 @@ def frame_loop(renderer, scene, params, frames=1, spp=32, splits=(4, 4), out_dir
     images = []
     for j in range(1, frames + 1):
         fb = renderer.new_framebuffer(W, H)
+        tag = checkpoint_tag(scene, params, cam, spp, splits) if checkpoint else None
         if checkpoint and j == 1 and os.path.exists(checkpoint):
-            old = Framebuffer.load(checkpoint)
-            if old.counts.shape == (H, W):
+            # a truncated file (a kill during an earlier write of a non-atomic writer) or a checkpoint of another
+            # frame -- other scene, camera, seed, size, spp or tiling -- is ignored, never mixed into this frame
+            try:
+                old, old_tag = Framebuffer.load(checkpoint), Framebuffer.load_tag(checkpoint)
+            except Exception as e:              # noqa: BLE001
+                old, old_tag = None, None
+                log(f">> ignoring {checkpoint}: {type(e).__name__}: {e}")
+            if old is not None and old.counts.shape == (H, W) and old_tag == tag:
                 fb = old
                 log(f">> resuming {checkpoint}: {int(fb.counts.sum())} of {W * H * spp} samples done")
+            elif old is not None:
+                log(f">> ignoring {checkpoint}: it belongs to another frame (tag {old_tag}, this frame {tag})")
         stats = Stats(W * H * spp)
         renderer.bvh.reset_counters()
         for i in range(sx * sy):                               # tile i covers block (i % splitsX, i / splitsX)
@@ -145,7 +169,7 @@ def frame_loop(renderer, scene, params, frames=1, spp=32, splits=(4, 4), out_dir
             c = renderer.bvh.counters()
             log(stats.update(int(c.diffuse_events), int(c.samples)))
             if checkpoint and j == 1:
-                fb.save(checkpoint)
+                fb.save(checkpoint, tag=tag)
         rgba = renderer.to_rgba(fb)
         images.append(rgba)
         if out_dir:

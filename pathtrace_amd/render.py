@@ -50,10 +50,17 @@ class Framebuffer:
     # Checkpoint / resume.  The reference has none (its only outputs are PNGs, main.go:770-778, :916-924); the sums and
     # counts ARE the whole state of a frame in progress, and because a sample's RNG stream is keyed by (pixel, sample
     # number), rendering samples [n, m) into a reloaded framebuffer gives the same sums as never having stopped.
-    def save(self, path):
-        """Write the accumulation state (f32 sums, u32 counts) as an .npz file."""
-        with open(path, "wb") as f:
-            np.savez(f, accum=self.accum, counts=self.counts)
+    def save(self, path, tag=None):
+        """Write the accumulation state (f32 sums, u32 counts) as an .npz file; `tag` = a string that names the frame
+        (driver.checkpoint_tag).  The file is written beside `path` and renamed over it, so a kill during the write
+        leaves the previous checkpoint whole."""
+        import os
+        tmp = f"{path}.tmp"
+        with open(tmp, "wb") as f:
+            np.savez(f, accum=self.accum, counts=self.counts, tag=np.frombuffer((tag or "").encode(), np.uint8))
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, path)
 
     @staticmethod
     def load(path) -> "Framebuffer":
@@ -62,6 +69,12 @@ class Framebuffer:
         if accum.ndim != 3 or accum.shape[2] != 3 or counts.shape != accum.shape[:2]:
             raise ValueError(f"{path}: not a framebuffer checkpoint (accum {accum.shape}, counts {counts.shape})")
         return Framebuffer(accum, counts)
+
+    @staticmethod
+    def load_tag(path):
+        """The tag a checkpoint was saved with ("" for one saved without)."""
+        with np.load(path, allow_pickle=False) as z:
+            return bytes(z["tag"]).decode() if "tag" in z.files else ""
 
     @property
     def samples_done(self) -> int:

@@ -355,12 +355,25 @@ def test_checkpoint_and_resume(gpu_ctx, tmp_path):
     started = r.new_framebuffer(64, 48)
     for i in range(5):
         r.render_tile(started, p, sc.camera, ((i % 4) * 16, (i // 4) * 12, 16, 12), spp=4 if i < 2 else 2)
-    started.save(tmp_path / "loop.npz")
+    tag = driver.checkpoint_tag(sc, p, sc.camera, 4, (4, 4))
+    started.save(tmp_path / "loop.npz", tag=tag)
     lines = []
     got = driver.frame_loop(r, sc, p, frames=1, spp=4, log=lines.append, checkpoint=str(tmp_path / "loop.npz"))[0]
     assert np.array_equal(got, want)
     assert sum("rays/s" in l for l in lines) == 14 and any("resuming" in l for l in lines)
-    assert Framebuffer.load(tmp_path / "loop.npz").samples_done == 4
+    assert Framebuffer.load(tmp_path / "loop.npz").samples_done == 4 and Framebuffer.load_tag(tmp_path / "loop.npz") == tag
+    assert not (tmp_path / "loop.npz.tmp").exists()                  # written beside the file and renamed over it
+    # a checkpoint of another frame (other seed) or a truncated file is ignored, not mixed into this frame
+    p2 = make_params(64, 48, bounces=2, seed=5)
+    want2 = driver.frame_loop(r, sc, p2, frames=1, spp=4, log=lambda _l: None)[0]
+    for spoil in (False, True):
+        if spoil:
+            raw = (tmp_path / "loop.npz").read_bytes()
+            (tmp_path / "loop.npz").write_bytes(raw[: len(raw) // 2])
+        lines = []
+        got2 = driver.frame_loop(r, sc, p2, frames=1, spp=4, log=lines.append, checkpoint=str(tmp_path / "loop.npz"))[0]
+        assert np.array_equal(got2, want2) and any("ignoring" in l for l in lines) and not any("resuming" in l for l in lines)
+        assert sum("rays/s" in l for l in lines) == 16
 
 
 def test_render_profile_adds_up_and_changes_nothing(gpu_ctx):

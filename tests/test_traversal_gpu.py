@@ -323,3 +323,44 @@ def test_deepest_stack_a_tree_can_ask_for(gpu_ctx, depth, monkeypatch):
         _check(UploadLinearBVH(v, f, arrays, ctx=ctx), orc, o, d, 1000.0, f"caterpillar{depth}/one-shot")
     finally:
         ctx.close()
+
+
+def test_small_host_batches_after_a_large_one(gpu_ctx):
+    """ptmi_closest_hit stages prim ids and t in two 256-byte-aligned halves of its output area: batches whose 4 n is
+    not a multiple of 256 (n = 1, 32, 65, 4097) must get the area the layout uses, whatever an earlier call sized
+    the staging buffer for."""
+    v, f = scenes.make_soup(3000, 21)
+    box = BuildBVH(v, f)
+    bvh = ConstructLinearBVH(box, ctx=gpu_ctx)
+    orc = oracle_lib.OracleBVH(v, f, linear=box.linear())
+    o, d = random_rays(v, 70000, 9)
+    _check(bvh, orc, o, d, 1000.0, "host batch 70000")
+    for n in (1, 32, 65, 4097):
+        _check(bvh, orc, o[:n], d[:n], 1000.0, f"host batch {n}")
+
+
+def test_more_launches_in_flight_than_cursor_lines(gpu_ctx):
+    """The persistent batch kernels take their ray cursor from a ring of 64 lines per context.  150 asynchronous launches
+    on three streams: the ring wraps twice, a line is only reused once its previous launch has finished (an event per
+    line), and every launch's answers equal the first launch's."""
+    import torch
+    v, f = scenes.make_soup(20000, 12)
+    box = BuildBVH(v, f)
+    bvh = ConstructLinearBVH(box, ctx=gpu_ctx)
+    o, d = random_rays(v, 40000, 3)
+    dev = torch.device("cuda", 0)
+    O, D = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    T = torch.full((o.shape[0],), 1000.0, dtype=torch.float32, device=dev)
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    torch.cuda.synchronize()
+    outs = []
+    for k in range(150):
+        P = torch.full((o.shape[0],), -7, dtype=torch.int32, device=dev)
+        t = torch.full((o.shape[0],), -1.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize() if k == 0 else None
+        bvh.CheckIntersectionDevice(O, D, T, P, t, streams[k % 3].cuda_stream)
+        outs.append((P, t))
+    torch.cuda.synchronize()
+    for P, t in outs[1:]:
+        assert torch.equal(P, outs[0][0]) and torch.equal(t.view(torch.int32), outs[0][1].view(torch.int32))
+    assert int((outs[0][0] >= 0).sum()) > 1000
