@@ -275,6 +275,7 @@ extern "C" int ptmi_create(int device, ptmi_ctx **out) {
         if (const char *v = getenv("PTMI_POOL_PATHS")) ctx->pool_paths = std::max(1 << 16, std::min(1 << 26, atoi(v)));
         if (const char *v = getenv("PTMI_POOL_GIB")) ctx->pool_bytes_max = (uint64_t)std::max(1, atoi(v)) << 30;
         if (const char *v = getenv("PTMI_RENDER_LANES")) ctx->render_lanes = atoi(v);
+        if (const char *v = getenv("PTMI_SHADE_SPLIT")) ctx->shade_split = atoi(v);
         if (const char *v = getenv("PTMI_RENDER_BATCH_ITERS")) ctx->render_batch_iters = std::max(1, atoi(v));
         if (const char *v = getenv("PTMI_CONNECT_VOTE")) ctx->connect_vote = atoi(v);
         if (const char *v = getenv("PTMI_SEGMENT_SHORTCUT")) ctx->segment_shortcut = atoi(v);

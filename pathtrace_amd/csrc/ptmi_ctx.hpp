@@ -79,6 +79,7 @@ struct ptmi_ctx {
     int render_vote_refill_min = 32;    // ... and idle lanes that trigger a refill there (the batch kernels: vote_refill_min)
     int segment_shortcut = 1;           // the curved march skips the walk for segments far outside the tree's tight box
     int connect_vote = 1;               // connect as a vote-scheduled persistent kernel (0: one-shot waves always)
+    int shade_split = 1;                // shade by class with the lean kernels (0: everything through the general kernel)
     int render_lanes = -1;              // independent wavefront loops side by side on two streams (1 .. 4; -1: 2 or 1 by tree size, render_core)
     int render_batch_iters = 2;         // wavefront iterations enqueued between two looks at the queue counters (render_core)
     int vote_refill_min = 16;           // refill once this many lanes are idle

@@ -57,7 +57,8 @@ enum {
     // A frame is one 128-byte line in memory (32 words, the last one unused) and FRW words of LDS while it is on top.
     NF = 31, FRW = 31
 };
-enum { FL_SPECULAR = 1, FL_FLIPPED = 2 };
+// FL_ANC: a frame below this call waits for its refraction subtree (PH_REFR_WAIT); inherited by every child
+enum { FL_SPECULAR = 1, FL_FLIPPED = 2, FL_ANC = 4 };
 // what the top frame is waiting for
 enum { PH_EXTEND = 0, PH_REFR_WAIT = 1, PH_SHADOW_WAIT = 2, PH_GI_WAIT = 3, PH_REFL_WAIT = 4 };
 enum { HS_MISS = 0, HS_HIT = 1, HS_HORIZON = 2 };
@@ -67,9 +68,33 @@ enum { HS_MISS = 0, HS_HIT = 1, HS_HORIZON = 2 };
 // beyond NSB-1 share the last bucket): a wave of the connect kernel then holds rays of one kind, which have similar
 // directions and lengths, instead of a mix in which the short ones idle until the longest has finished.
 enum { NSB = 8 };
-enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHP0 = 2, QC_SHP1 = 3, QC_FREE = 4, QC_SRAY = 5, QC_NEXT = QC_SRAY + NSB,   // QC_NEXT: next sample id to generate
+// ---- shading by class ------------------------------------------------------------------------------------------
+// A shade wave that holds a random mix of misses, glass hits, diffuse hits and returning frames executes the union of
+// their code (round 2: lane utilisation 0.62, 2 100 wave instructions per wave-visit).  The extend queue is therefore
+// sorted by CLASS before it is shaded: extend, which knows the hit, writes one class byte per entry (classify());
+// bin_kernel turns the bytes into one index list per class; and three kernels shade the lists, each thread gathering
+// the record of the entry its list names:
+//   shade_ret_kernel   a call that returns at once (miss, horizon, failed entry test) and unwinds to the primary
+//                      sample -- and the frames parked for their shadow rays, which unwind the same way.  No LDS frame,
+//                      no staging: registers and the parked frames.
+//   shade_diff_kernel  a fresh hit on a plain diffuse surface: HandleDiffuseMaterial's direct lighting + the GI child
+//                      (tracer.go:443-648), straight-line code that ends by parking the frame.
+//   shade_kernel       everything else (glass, reflective, emissive hit on an indirect ray, accretion disk, any path
+//                      under a refraction frame, scatterRays > 1): the general state machine, its waves sorted by
+//                      sub-class.
+// Class codes (one byte per queue entry, written by extend):
+enum { C_RET = 0, C_RET_ANC = 1, C_DIFF = 2, C_DIFF_LEAF = 3, C_GLASS = 4, C_REFL = 5, C_MID = 6, C_EMIT = 7, C_OTHER = 8, C_CODES = 9 };
+// Index lists (bin_kernel maps a code to a list with a table the host fills: render_core):
+enum { L_RET = 0, L_DIFF = 1, L_GEN = 2,                                 // the general kernel's lists, each padded to whole waves:
+       L_G_RET = L_GEN, L_G_GLASS, L_G_REFL, L_G_MID, L_G_EMIT, L_G_DIFF, L_G_OTHER, NLIST, N_GEN = NLIST - L_GEN };
+// what extend knows about a triangle's material (one byte per triangle, ptmi_upload_scene): tracer.go:49 / :95 / :116-118
+enum { TC_GLASS = 1, TC_ACCR = 2, TC_REFL = 4, TC_MID = 8, TC_EMIT = 16 };
+// what extend knows about the pending call (bits 26.. of the record's slot word)
+enum { CTX_SHIFT = 26, CTX_FAIL = 1, CTX_ANC = 2, CTX_B0 = 4, CTX_BI = 8, SLOT_MASK = (1 << CTX_SHIFT) - 1 };
+enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHP0 = 2, QC_SHP1 = 3, QC_SHA0 = 4, QC_SHA1 = 5, QC_FREE = 6, QC_SRAY = 7, QC_NEXT = QC_SRAY + NSB,   // QC_NEXT: next sample id to generate
        QC_CURSOR = QC_NEXT + 1, QC_CURSOR_EXT = QC_CURSOR + 1,                  // ray cursors of the vote-scheduled kernels
-       QC_COUNT = QC_CURSOR_EXT + 1, QC_STRIDE = 16 };
+       QC_LIST = QC_CURSOR_EXT + 1,                                             // lengths of the index lists (bin_kernel)
+       QC_COUNT = QC_LIST + NLIST, QC_STRIDE = 16 };
 struct ShadowCounts { uint32_t n[NSB]; };
 // The wavefront loop is driven from the device: at the start of an iteration a one-thread kernel (iter_prep_kernel)
 // turns the queue counters the last shade pass left behind into this iteration's arguments -- one 128-byte line that
@@ -79,33 +104,43 @@ struct ShadowCounts { uint32_t n[NSB]; };
 struct IterArgs {
     uint32_t n_ext;                // entries of the extend queue to trace and shade (this iteration's fresh samples included)
     uint32_t gen_n, gen_base;      // fresh samples to generate: entries gen_base .. gen_base + gen_n - 1, slots from the free list
-    uint32_t n_shp;                // parked frames whose shadow rays are answered in this iteration
+    uint32_t n_shp, n_sha;         // parked frames whose shadow rays are answered in this iteration: lean (shade_ret_kernel) / general
     ShadowCounts sray;             // shadow rays per bucket
-    uint32_t pad[3];
+    uint32_t pad[2];
     unsigned long long first_sample;
 };
 static_assert(sizeof(IterArgs) <= 128, "IterArgs is one line");
-// Path state that travels with the queues (no per-path header in memory):
-//   extend queue entry i = the pending TraceRay call of a path, three coalesced arrays per queue buffer:
-//     q_ext_ray[2i], [2i+1]  (o.xyz, bits(slot)) / (d.xyz, V_t at the start of the geodesic -- curved rays only)
-//     q_ext_arg[3i..3i+2]    (sample id, RNG key, RNG counter, depth | tracker length << 8)
-//                            (bounces, bounceIndex, flags, energy)           -- the arguments of the call (tracer.go:15)
-//                            (lastSurfaceNormal.xyz, tracker entry 0)
-//     q_ext_hit[i]           (hit status, primitive, t, V_t now)             -- written by extend
-//   shadow-wait queue entry = a parked frame waiting for connect's answers, 2 x float4:
-//     (bits(slot), sample id, RNG key, RNG counter) / (depth | tracker length << 8, tracker entry 0, -, -)
+// Path state that travels with the queues (no per-path header in memory).
+//   Extend queue entry = the pending TraceRay call of a path: ONE record of whole 64-byte sectors (REC words; 128 bytes
+//   for straight rays with up to three shadow-ray kinds), because the shade kernels gather records in class order and a
+//   gathered record must not share its sectors with another entry (a [field][entry] layout read through a permutation
+//   fetches every sector about twice).  Words:
+//      0-2  ray origin             3  slot | CTX_* << 26          4-6  ray direction       7  sample id
+//      8    hit: status << 30 | primitive (30 bits)      9  t     -- written by extend (one 8-byte store)
+//     10    RNG key     11  RNG counter
+//     12    depth | tracker length << 8 | bounces << 16 (int8) | bounceIndex << 24
+//     13    flags | shadow-term mask << 8       14  energy       15  tracker entry 0      16-18  lastSurfaceNormal
+//     19..  shadow terms of the caller's rays, 4 words each (term.xyz, position of the ray in the shadow-ray queue):
+//           the first REC_INLINE (3; curved rays 2) in words 19.., the others from word 32 on
+//     28-29 (curved rays) V_t at the end / at the start of the geodesic -- written by extend
+//   Shade writes a wave's records as whole lines (they are contiguous in the next queue), extend reads the first 32
+//   bytes and answers into words 8-9.
+//   shadow-wait queue entry = a parked frame waiting for connect's answers, 2 x float4 + nshadow terms:
+//     (bits(slot), sample id, RNG key, RNG counter) / (depth | tracker length << 8, tracker entry 0, term mask, flags)
+//   Lean entries (no refraction frame below them, scatterRays == 1) fill the queue from the front and are unwound by
+//   shade_ret_kernel, the others fill it from the back (entry cap-1-k) and go to the general kernel.
 // A pending call has no state beyond its arguments, so a fresh sample and a pushed child touch no per-path memory at
-// all: shade reads them from the queue (coalesced), extend answers into the queue, and frame memory is only touched
-// when a frame is parked under a child or waits for its shadow rays.  (Round 1 kept this state in a 128-byte header
-// line per path: 80 bytes read and 64 written per visit, scattered, plus extend's 12-byte partial-line write.)
+// all, and frame memory is only touched when a frame is parked under a child or waits for its shadow rays.
 // Tracker entries beyond the first live in Pool::trk and are only touched by glass hits.
-enum { QA = 3 };
+enum { R_O = 0, R_SLOT = 3, R_D = 4, R_SID = 7, R_HIT = 8, R_T = 9, R_KEY = 10, R_CTR = 11, R_PACK = 12, R_FLAGS = 13, R_ENERGY = 14,
+       R_TRK0 = 15, R_LN = 16, R_TERMS = 19, R_VT = 28, REC_BASE = 32 };
 
 // self-check failures reported through counters[CNT_ERROR] (a corrupted path is dropped, never dereferenced)
-enum { ERR_SLOT = 1, ERR_DEPTH = 2, ERR_PRIM = 4, ERR_MAT = 8, ERR_PHASE = 16, ERR_QUEUE = 32 };
+enum { ERR_SLOT = 1, ERR_DEPTH = 2, ERR_PRIM = 4, ERR_MAT = 8, ERR_PHASE = 16, ERR_QUEUE = 32, ERR_CLASS = 64 };
 
 struct DevScene {
     const float4 *stri;                  // shading record per triangle, 5 x float4: A B C, N0 N1 N2, material id
+    const uint8_t *tri_class;            // TC_* bits per triangle (classify)
     uint32_t ntris, nmats;
     const float *uvs; const TexDesc *tex; const uint32_t *tex_pixels; uint32_t ntex;   // vnmu.UVs + CachedImage table
     const PtMaterial *mats; const uint32_t *emissive; uint32_t nemissive;
@@ -147,14 +182,16 @@ static uint64_t lane_sample_count(uint64_t total, uint32_t lane, uint32_t nlanes
 struct Pool {
     uint32_t cap;
     int nframes, ntrk, nshadow;          // bounces+1, tracker history capacity (multiple of 4), nlights+2
+    int rec_q;                           // float4s per extend-queue record (REC / 4; a multiple of 4: whole 64-byte sectors)
+    int rec_inline;                      // shadow terms held in words 19.. of a record (the others from word 32 on)
     float4 *fr;                          // [cap][nframes][8]   frames (F_*)
     float *trk;                          // [cap][ntrk]         RefractiveIndexTracker.indices 1 .. (entry 0 travels with the path)
     // queues
-    float4 *q_ext_ray[2];                // extend queue (double buffered), 2 x float4 per entry: (o.xyz, bits(slot)) / (d.xyz, V_t0)
-    float4 *q_ext_arg[2];                // ... its pending-call state, QA x float4 per entry
-    float4 *q_ext_hit;                   // ... extend's answer, one float4 per entry of the queue being traced
-    float4 *q_shpath[2];                 // paths waiting for their shadow rays, 2 x float4 per entry
-    float4 *q_ext_sh[2], *q_shp_sh[2];   // shadow terms that travel with an entry of either queue: nshadow x (term.xyz, bits(position of the ray))
+    float4 *q_rec[2];                    // extend queue (double buffered): one record per entry (R_*)
+    uint8_t *q_cls;                      // class code of every entry of the queue being traced (extend)
+    uint32_t *q_idx;                     // [NLIST][cap] entries of the queue being shaded, by list (bin_kernel)
+    float4 *q_shpath[2];                 // paths waiting for their shadow rays, 2 x float4 per entry: lean ones from the front, the others from the back
+    float4 *q_shp_sh[2];                 // ... their shadow terms: nshadow x (term.xyz, bits(position of the ray))
     float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, -)
     uint32_t *q_sray_occ;                // connect's answers, by position in the shadow-ray queue (0 free, 1 occluded)
     uint32_t *q_free;                    // slots that finished in the last shade pass
@@ -162,6 +199,9 @@ struct Pool {
     IterArgs *it;                        // this iteration's arguments (iter_prep_kernel)
     float *out;                          // per-sample radiance [total][3]
 };
+__device__ __forceinline__ float4 *rec_at(const Pool &pl, int buf, size_t entry) { return pl.q_rec[buf] + entry * (size_t)pl.rec_q; }
+// word offset of shadow term k inside a record
+__device__ __forceinline__ int term_word(const Pool &pl, int k) { return k < pl.rec_inline ? R_TERMS + 4 * k : REC_BASE + 4 * (k - pl.rec_inline); }
 
 __device__ __forceinline__ uint32_t wave_append(unsigned long long *counter, bool pred) {
     // one atomic per wave: ballot, popcount, prefix by lane
@@ -216,9 +256,9 @@ __global__ void iter_prep_kernel(Pool pl, int cur, unsigned long long total, uns
     if (blockIdx.x || threadIdx.x) return;
     auto qc = [&](int w) -> unsigned long long & { return pl.qcnt[(size_t)w * QC_STRIDE]; };
     const int nxt = cur ^ 1;
-    unsigned long long n_ext = qc(QC_EXT0 + cur), n_shp = qc(QC_SHP0 + cur), n_free = qc(QC_FREE), next = qc(QC_NEXT);
+    unsigned long long n_ext = qc(QC_EXT0 + cur), n_shp = qc(QC_SHP0 + cur), n_sha = qc(QC_SHA0 + cur), n_free = qc(QC_FREE), next = qc(QC_NEXT);
     IterArgs a;
-    bool bad = n_ext > pl.cap || n_shp > pl.cap || n_free > pl.cap || next > total;
+    bool bad = n_ext > pl.cap || n_shp + n_sha > pl.cap || n_free > pl.cap || next > total;
     for (int b = 0; b < NSB; ++b) {
         const unsigned long long n = qc(QC_SRAY + b);
         const unsigned long long room = b < NSB - 1 ? (unsigned long long)pl.cap : (unsigned long long)pl.cap * (unsigned long long)max(pl.nshadow - (NSB - 1), 0);
@@ -227,34 +267,81 @@ __global__ void iter_prep_kernel(Pool pl, int cur, unsigned long long total, uns
     }
     if (bad) {          // a counter out of range: raise the error word and let the pool run dry
         atomicOr(&counters[CNT_ERROR], (unsigned long long)ERR_QUEUE);
-        n_ext = n_shp = n_free = 0; next = total;
+        n_ext = n_shp = n_sha = n_free = 0; next = total;
         for (int b = 0; b < NSB; ++b) a.sray.n[b] = 0;
     }
     unsigned long long ng = min(n_free, total - next);
     if (n_ext + ng > pl.cap) ng = pl.cap - n_ext;
     a.gen_n = (uint32_t)ng; a.gen_base = (uint32_t)n_ext; a.first_sample = next;
-    a.n_ext = (uint32_t)(n_ext + ng); a.n_shp = (uint32_t)n_shp;
-    a.pad[0] = a.pad[1] = a.pad[2] = 0;
+    a.n_ext = (uint32_t)(n_ext + ng); a.n_shp = (uint32_t)n_shp; a.n_sha = (uint32_t)n_sha;
+    a.pad[0] = a.pad[1] = 0;
     *pl.it = a;
     qc(QC_NEXT) = next + ng;
     qc(QC_EXT0 + cur) = n_ext + ng;
-    qc(QC_EXT0 + nxt) = 0; qc(QC_SHP0 + nxt) = 0; qc(QC_FREE) = 0;
+    qc(QC_EXT0 + nxt) = 0; qc(QC_SHP0 + nxt) = 0; qc(QC_SHA0 + nxt) = 0; qc(QC_FREE) = 0;
     for (int b = 0; b < NSB; ++b) qc(QC_SRAY + b) = 0;
+    for (int l = 0; l < NLIST; ++l) qc(QC_LIST + l) = 0;
     qc(QC_CURSOR) = 0; qc(QC_CURSOR_EXT) = 0;
 }
 
-// A fresh sample is a pending call and nothing else: one ray entry and one argument entry at the end of the extend
-// queue (no atomic: entry gen_base + i), both written coalesced; its slot comes from the free list.
+// ---- whole-line stores ------------------------------------------------------------------------------------------
+// A lane that stores a 128-byte line of its own (a parked frame, a queue record) with eight 16-byte stores touches
+// 16 bytes of 64 different lines per instruction.  Instead the wave exchanges the lines through LDS and lane 8 g + j
+// writes quarter-line j of the lines of lanes 8 g .. 8 g + 7 in turn: every store instruction then covers eight whole
+// lines.  `col` = this lane's column of an LDS area laid out [word][stride] that holds its line (word w at
+// col[w * stride]); dst = where the line goes (nullptr: this lane has none); nwords <= 32, the rest of the line is 0.
+__device__ __forceinline__ void wave_store_lines(const float *col, int stride, float4 *dst, int nwords) {
+    const unsigned long long m_st = __ballot(dst != nullptr);
+    if (!m_st) return;
+    const int lane = threadIdx.x & 63, grp = lane & ~7, sub = lane & 7;
+    const uint32_t lo = (uint32_t)(uintptr_t)dst, hi = (uint32_t)((uintptr_t)dst >> 32);
+    const float *base = col - lane;                                  // column of lane 0 of this wave
+    for (int i = 0; i < 8; ++i) {
+        const int src = grp + i;
+        const uint32_t slo = (uint32_t)__shfl((int)lo, src), shi = (uint32_t)__shfl((int)hi, src);
+        if (m_st >> src & 1ull) {
+            float4 *d = (float4 *)(((uintptr_t)shi << 32) | (uintptr_t)slo);
+            const float *c = base + src;
+            d[sub] = make_float4(4 * sub < nwords ? c[(4 * sub) * stride] : 0.0f, 4 * sub + 1 < nwords ? c[(4 * sub + 1) * stride] : 0.0f,
+                                 4 * sub + 2 < nwords ? c[(4 * sub + 2) * stride] : 0.0f, 4 * sub + 3 < nwords ? c[(4 * sub + 3) * stride] : 0.0f);
+        }
+    }
+}
+
+// What extend tells the binning about an entry (C_*): tracer.go's branches in the order TraceRay takes them -- the
+// entry test (:16), miss / horizon (:250-263), glass (:49), the accretion disk (:95), reflectivity (:116-163), an
+// emitter seen by an indirect ray (:461-465), and the plain diffuse surface with or without bounces left (:622).
+__device__ __forceinline__ uint32_t classify(int status, int prim, uint32_t ctx, const uint8_t *__restrict__ tri_class) {
+    if (status != HS_HIT || (ctx & CTX_FAIL)) return (ctx & CTX_ANC) ? C_RET_ANC : C_RET;
+    const uint32_t tc = tri_class[prim];
+    if (tc & TC_GLASS) return C_GLASS;
+    if (tc & TC_ACCR) return C_OTHER;
+    if (tc & TC_REFL) return C_REFL;
+    if (tc & TC_MID) return C_MID;
+    if ((tc & TC_EMIT) && (ctx & CTX_BI)) return C_EMIT;
+    return (ctx & CTX_B0) ? C_DIFF_LEAF : C_DIFF;
+}
+// CTX_* bits of a pending call with these arguments
+__device__ __forceinline__ uint32_t call_ctx(int bounces, int bindex, float energy, uint32_t flags) {
+    return ((bounces < 0 || energy < (float)1e-2) ? (uint32_t)CTX_FAIL : 0u) | ((flags & FL_ANC) ? (uint32_t)CTX_ANC : 0u) |
+           (bounces <= 0 ? (uint32_t)CTX_B0 : 0u) | (bindex > 0 ? (uint32_t)CTX_BI : 0u);
+}
+__device__ __forceinline__ uint32_t pack_call(int depth, uint32_t trk_len, int bounces, int bindex) {
+    return ((uint32_t)depth & 0xFFu) | (trk_len & 0xFFu) << 8 | ((uint32_t)bounces & 0xFFu) << 16 | ((uint32_t)bindex & 0xFFu) << 24;
+}
+
+// A fresh sample is a pending call and nothing else: one record at the end of the extend queue (no atomic: entry
+// gen_base + i), written as whole lines; its slot comes from the free list.
 __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, int cur) {
-    // the 256 entries a workgroup writes per trip are contiguous in both arrays (8 KB of rays, 12 KB of arguments), so
-    // they are staged in LDS and written out as whole lines: per-thread stores 32 / 48 bytes apart reach 3.2 TB/s
-    __shared__ float4 s_ray[2 * 256], s_arg[QA * 256];
+    // the 256 records a workgroup writes per trip are contiguous, so they are put together in LDS ([word][thread]) and
+    // written out as whole lines (per-thread 16-byte stores 128 bytes apart reach 3.2 TB/s)
+    __shared__ float s_rec[20 * 256];
     const uint32_t n = pl.it->gen_n, q_base = pl.it->gen_base;
     const unsigned long long first_sample = pl.it->first_sample;
-    float4 *q_ray = pl.q_ext_ray[cur], *q_arg = pl.q_ext_arg[cur];
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
-        const uint32_t i = i0 + threadIdx.x, m = min(256u, n - i0);             // m entries in this trip
+        const uint32_t i = i0 + threadIdx.x;
+        float4 *dst = nullptr;
         if (i < n) {
             const uint32_t slot = pl.q_free[i];
             const uint32_t sid = (uint32_t)lane_sample_id(first_sample + i, ra.lane, ra.nlanes);   // total < 2^32/3 (render_core)
@@ -268,20 +355,24 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, i
             const V3 pos = mk(ra.cam.position), fwd = mk(ra.cam.forward), right = mk(ra.cam.right), up = mk(ra.cam.up);
             const V3 rayOrigin = add(add(add(pos, scale(fwd, ra.cam.frustum_distance)), scale(up, py)), scale(right, px));
             const V3 d = normalize(mk(rayOrigin.x - pos.x, rayOrigin.y - pos.y, rayOrigin.z - pos.z));
-            float4 *qr = s_ray + 2 * threadIdx.x;
-            qr[0] = make_float4(pos.x, pos.y, pos.z, u2f(slot));
-            qr[1] = make_float4(d.x, d.y, d.z, 1.0f);
-            // TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0; shade handles that case
-            float4 *qa = s_arg + QA * threadIdx.x;
-            qa[0] = make_float4(u2f(sid), u2f(rng.key), u2f(rng.ctr), u2f(0u | (1u << 8)));           // depth 0, tracker {1.0}
-            qa[1] = make_float4(i2f(ra.p.bounces), i2f(0), u2f(0u), 1.0f);                            // main.go:875
-            qa[2] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);                                              // lastSurfaceNormal {}, NewRefractiveIndexTracker(1.0)
+            // main.go:875: bounceIndex 0, lastSurfaceNormal {}, not specular, NewRefractiveIndexTracker(1.0), energy 1.0.
+            // TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0 (CTX_FAIL).
+            float *w = s_rec + threadIdx.x;
+            w[R_O * 256] = pos.x; w[(R_O + 1) * 256] = pos.y; w[(R_O + 2) * 256] = pos.z;
+            w[R_SLOT * 256] = u2f(slot | call_ctx(ra.p.bounces, 0, 1.0f, 0u) << CTX_SHIFT);
+            w[R_D * 256] = d.x; w[(R_D + 1) * 256] = d.y; w[(R_D + 2) * 256] = d.z;
+            w[R_SID * 256] = u2f(sid);
+            w[R_HIT * 256] = 0.0f; w[R_T * 256] = 0.0f;
+            w[R_KEY * 256] = u2f(rng.key); w[R_CTR * 256] = u2f(rng.ctr);
+            w[R_PACK * 256] = u2f(pack_call(0, 1u, ra.p.bounces, 0));                                  // depth 0, tracker {1.0}
+            w[R_FLAGS * 256] = u2f(0u);
+            w[R_ENERGY * 256] = 1.0f; w[R_TRK0 * 256] = 1.0f;
+            w[R_LN * 256] = 0.0f; w[(R_LN + 1) * 256] = 0.0f; w[(R_LN + 2) * 256] = 0.0f; w[R_TERMS * 256] = 0.0f;
+            dst = rec_at(pl, cur, (size_t)q_base + i);
         }
-        __syncthreads();
-        float4 *dr = q_ray + 2 * ((size_t)q_base + i0), *da = q_arg + QA * ((size_t)q_base + i0);
-        for (uint32_t j = threadIdx.x; j < 2 * m; j += 256) dr[j] = s_ray[j];
-        for (uint32_t j = threadIdx.x; j < QA * m; j += 256) da[j] = s_arg[j];
-        __syncthreads();
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own LDS writes, before its lanes read them
+        wave_store_lines(s_rec + threadIdx.x, 256, dst, 20);
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
@@ -298,12 +389,12 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
     __shared__ uint32_t smem[STACK * WAVE];
     const uint32_t n = pl.it->n_ext;
     if (n >= vote_from) return;
-    float4 *__restrict__ qray = pl.q_ext_ray[cur];
     uint32_t nq = 0;
     for (uint32_t base = blockIdx.x * WAVE; base < n; base += gridDim.x * WAVE) {
         const uint32_t i = base + threadIdx.x;
         if (i >= n) continue;
-        const float4 qa = qray[2 * (size_t)i], qb = qray[2 * (size_t)i + 1];
+        float4 *rec = rec_at(pl, cur, i);
+        const float4 qa = rec[0], qb = rec[1];
         V3 o = mk(qa.x, qa.y, qa.z);
         V3 d = mk(qb.x, qb.y, qb.z);
         RayState st = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -330,12 +421,16 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
                 if (dot(rel, rel) <= sc.bh.rs * sc.bh.rs) { status = HS_HORIZON; break; }   // :250-255
             }
         }
-        pl.q_ext_hit[i] = make_float4(i2f(status), i2f(prim), t, CURVED ? st.vt : 1.0f);
-        // shade reads the ray from this entry (same index in its list): the origin of a hit (tracer.go:37 adds t to
-        // the CURRENT origin) and, for a curved ray, the direction it ended with (the sky lookup of a miss, :260-263)
-        if (CURVED || (moved && status == HS_HIT)) {
-            qray[2 * (size_t)i] = make_float4(o.x, o.y, o.z, qa.w);
-            qray[2 * (size_t)i + 1] = make_float4(d.x, d.y, d.z, vt0);
+        ((float2 *)rec)[R_HIT / 2] = make_float2(u2f((uint32_t)status << 30 | ((uint32_t)prim & 0x3FFFFFFFu)), t);
+        pl.q_cls[i] = (uint8_t)classify(status, prim, f2u(qa.w) >> CTX_SHIFT, sc.tri_class);
+        // shade reads the ray from the record: the origin of a hit (tracer.go:37 adds t to the CURRENT origin) and,
+        // for a curved ray, the direction it ended with (the sky lookup of a miss, :260-263)
+        if (CURVED) {
+            rec[0] = make_float4(o.x, o.y, o.z, qa.w);
+            rec[1] = make_float4(d.x, d.y, d.z, qb.w);
+            ((float2 *)rec)[R_VT / 2] = make_float2(st.vt, vt0);
+        } else if (moved && status == HS_HIT) {
+            rec[0] = make_float4(o.x, o.y, o.z, qa.w);
         }
     }
     for (int off = 32; off > 0; off >>= 1) nq += __shfl_xor(nq, off);
@@ -344,36 +439,100 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
 
 // extend for straight rays with one segment per call (max_steps == 1, no black hole): persistent waves walking
 // vote-scheduled single steps (vote_walk, trav_device.hpp), queue entries dealt in chunks from one cursor.  Same output
-// as render_extend_kernel: the answer into the queue's hit array (a ray that is traced once never moves before a hit,
-// and shade does not look at the origin of a miss, so the entry itself is never written back).
+// as render_extend_kernel: the answer into the record (a ray that is traced once never moves before a hit, and shade
+// does not look at the origin of a miss, so the ray itself is never written back) and the entry's class byte.
 // A persistent wave reserves three chunks of queue entries before it starts (one in use, two ahead): the chunk is
 // `chunk_max` entries when the launch feeds every wave that much, less for smaller launches (never below one wave's 64).
 __device__ __forceinline__ uint32_t vote_chunk(uint64_t n, uint32_t chunk_max) {
     const uint64_t fair = n / (3ull * gridDim.x) / WAVE * WAVE;
     return (uint32_t)min((uint64_t)chunk_max, max((uint64_t)WAVE, fair));
 }
+struct ExtTag { uint32_t entry, ctx; };
 template <int STACK>
-__global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Pool pl, RenderArgs ra, int cur, uint32_t vote_from,
-                                                                  unsigned long long *counters, int refill_min, int tri_bias,
-                                                                  uint32_t chunk_max) {
+__global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Pool pl, const uint8_t *__restrict__ tri_class, RenderArgs ra,
+                                                                  int cur, uint32_t vote_from, unsigned long long *counters, int refill_min,
+                                                                  int tri_bias, uint32_t chunk_max) {
     __shared__ uint32_t smem[STACK * WAVE];
     const uint32_t n = pl.it->n_ext;
     if (n < vote_from || (uint64_t)blockIdx.x * WAVE >= n) return;          // the one-shot kernel takes small launches
-    const float4 *__restrict__ qray = pl.q_ext_ray[cur];
     const float step = ra.p.step_size;
     TravCounters cnt;
-    vote_walk<WAVE, false, false, uint32_t>(
+    vote_walk<WAVE, false, false, ExtTag>(
         bvh, smem + threadIdx.x, n, pl.qcnt + (size_t)QC_CURSOR_EXT * QC_STRIDE, refill_min, tri_bias, vote_chunk(n, chunk_max), cnt,
-        [&](uint64_t idx, NextRay &nx, uint32_t &entry) {
-            const float4 qa = qray[2 * (size_t)idx], qb = qray[2 * (size_t)idx + 1];
-            entry = (uint32_t)idx;
+        [&](uint64_t idx, NextRay &nx, ExtTag &tag) {
+            const float4 *rec = rec_at(pl, cur, idx);
+            const float4 qa = rec[0], qb = rec[1];
+            tag.entry = (uint32_t)idx; tag.ctx = f2u(qa.w) >> CTX_SHIFT;
             nx.ox = qa.x; nx.oy = qa.y; nx.oz = qa.z; nx.dx = qb.x; nx.dy = qb.y; nx.dz = qb.z; nx.tmax = step;
         },
-        [&](uint32_t entry, const RayTrav &r) {
+        [&](const ExtTag &tag, const RayTrav &r) {
             const bool hit = r.best >= 0;
-            pl.q_ext_hit[entry] = make_float4(i2f(hit ? HS_HIT : HS_MISS), i2f(r.best), hit ? r.best_t : 0.0f, 1.0f);
+            ((float2 *)rec_at(pl, cur, tag.entry))[R_HIT / 2] =
+                make_float2(u2f((uint32_t)(hit ? HS_HIT : HS_MISS) << 30 | ((uint32_t)r.best & 0x3FFFFFFFu)), hit ? r.best_t : 0.0f);
+            pl.q_cls[tag.entry] = (uint8_t)classify(hit ? HS_HIT : HS_MISS, r.best, tag.ctx, tri_class);
         });
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)n);
+}
+
+// ------------------------------------------------------------------------------------------ bin
+// Turns the class bytes extend wrote into one index list per class (the host's table maps a code to a list).  A
+// workgroup takes BIN_CHUNK consecutive entries, wave w the w-th quarter of them, and appends its entries of a list in
+// entry order: one atomic per workgroup and list (a few thousand per launch; they serialise at ~12 ns on a list's
+// counter line).  Within a chunk the order of the queue is kept, so neighbouring rays stay neighbours.
+enum { BIN_PER_LANE = 32, BIN_CHUNK = 256 * BIN_PER_LANE };
+struct BinMap { uint8_t list[16]; };
+__global__ __launch_bounds__(256) void bin_kernel(Pool pl, BinMap map) {
+    const uint32_t n = pl.it->n_ext;
+    const uint32_t chunk0 = blockIdx.x * (uint32_t)BIN_CHUNK;
+    if (chunk0 >= n) return;
+    __shared__ uint32_t s_cnt[NLIST][4], s_base[NLIST][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t first = chunk0 + (uint32_t)wv * (64u * BIN_PER_LANE);
+    uint32_t code[BIN_PER_LANE];          // list of entry first + 64 k + lane (NLIST: none)
+    uint32_t cnt[NLIST];
+#pragma unroll
+    for (int l = 0; l < NLIST; ++l) cnt[l] = 0;
+#pragma unroll
+    for (int k = 0; k < BIN_PER_LANE; ++k) {
+        const uint32_t e = first + 64u * k + lane;
+        uint32_t c = e < n ? pl.q_cls[e] : 0xFFu;
+        code[k] = c < (uint32_t)C_CODES ? map.list[c] : (uint32_t)NLIST;
+    }
+#pragma unroll
+    for (int k = 0; k < BIN_PER_LANE; ++k) {
+#pragma unroll
+        for (int l = 0; l < NLIST; ++l) cnt[l] += (uint32_t)__popcll(__ballot(code[k] == (uint32_t)l));     // wave-uniform
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < NLIST; ++l) s_cnt[l][wv] = cnt[l];
+    }
+    __syncthreads();
+    if (threadIdx.x < NLIST) {
+        const int l = threadIdx.x;
+        const uint32_t c0 = s_cnt[l][0], c1 = s_cnt[l][1], c2 = s_cnt[l][2], c3 = s_cnt[l][3], total = c0 + c1 + c2 + c3;
+        uint32_t base = 0;
+        if (total) base = (uint32_t)atomicAdd(&pl.qcnt[(size_t)(QC_LIST + l) * QC_STRIDE], (unsigned long long)total);
+        s_base[l][0] = base; s_base[l][1] = base + c0; s_base[l][2] = base + c0 + c1; s_base[l][3] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+    uint32_t pos[NLIST];
+#pragma unroll
+    for (int l = 0; l < NLIST; ++l) pos[l] = s_base[l][wv];
+#pragma unroll
+    for (int k = 0; k < BIN_PER_LANE; ++k) {
+        const uint32_t e = first + 64u * k + lane;
+#pragma unroll
+        for (int l = 0; l < NLIST; ++l) {
+            const unsigned long long m = __ballot(code[k] == (uint32_t)l);
+            if (code[k] == (uint32_t)l) {
+                const uint32_t at = pos[l] + (uint32_t)__popcll(m & lt);
+                if (at < pl.cap) pl.q_idx[(size_t)l * pl.cap + at] = e;
+            }
+            pos[l] += (uint32_t)__popcll(m);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ connect
@@ -451,6 +610,144 @@ __device__ __forceinline__ STri load_stri(const DevScene &sc, uint32_t prim) {
 }
 __device__ __forceinline__ bool is_emissive(const PtMaterial &m) { return m.ke[0] > 0.0f || m.ke[1] > 0.0f || m.ke[2] > 0.0f; }
 
+// (re)derives the hit of a frame from what the frame stores: ray, t, primitive, and whether the glass branch flipped
+// the normal (tracer.go:37-53, :468-514)
+__device__ __forceinline__ void derive_hit(const DevScene &sc, V3 ro, V3 rd, float t, int prim, bool flipped, Hit &h, uint32_t &err) {
+    h.ro = ro; h.rd = rd;
+    h.prim = prim;
+    if ((uint32_t)h.prim >= sc.ntris) { err |= ERR_PRIM; h.prim = 0; }
+    h.P = add(h.ro, scale(h.rd, t));                                        // tracer.go:37
+    STri tr = load_stri(sc, (uint32_t)h.prim);
+    if (tr.mat >= sc.nmats) { err |= ERR_MAT; tr.mat = 0; }
+    h.A = tr.A; h.B = tr.B; h.C = tr.C;
+    V3 n = normalize(interpolate_normal(h.P, h.A, h.B, h.C, tr.N0, tr.N1, tr.N2));   // :38-46
+    if (flipped) n = scale(n, -1.0f);                                       // :53
+    h.normal = n;
+    h.mat = tr.mat;
+    h.dnormal = n;
+    diffuse_surface(sc.mats[h.mat], sc.uvs, sc.tex, sc.ntex, sc.tex_pixels, (uint32_t)h.prim, h.P, h.A, h.B, h.C,
+                    h.albedo, h.dnormal);
+}
+
+// Direct lighting of HandleDiffuseMaterial (:523-618): draws in the reference's order and hands every shadow ray to
+// stage(kind, direction, range, term) -- `term` is what the final sum adds if the ray is free (lights: albedo *
+// Sample(...), :557-559).  The terms travel with the path's next queue entry and are summed at its next visit, once
+// `connect` has answered the rays.  Returns the kinds staged (bit k = kind k); sh_o / sh_eo = the rays' origins (sky
+// and light rays; emissive sample).
+template <typename Stage>
+__device__ __forceinline__ uint32_t direct_lighting(const DevScene &sc, const RenderArgs &ra, const Hit &h, Rng &rng, V3 &sh_o, V3 &sh_eo,
+                                                    uint32_t &err, Stage stage) {
+    const V3 albedo = h.albedo;
+    const V3 rayOrigin = add(h.P, scale(h.dnormal, (float)0.001));                       // :528
+    uint32_t need = 0;
+    sh_o = rayOrigin;
+    if (sc.sky.kind != PTMI_SKY_NONE) {                                                 // :531-542
+        V3 t1, t2; tangent_frame(h.dnormal, t1, t2);
+        V3 rn = cosine_sample2(rng, h.dnormal, t1, t2);
+        need |= 1u; stage(0, rn, 100000.0f, cmul(sky_sample(sc.sky, sc.sky_img, rn), albedo));
+    }
+    for (uint32_t li = 0; li < sc.nlights; ++li) {                                      // :545-560
+        const PtLight &L = sc.lights[li];
+        if (L.kind == PTMI_LIGHT_SUN) {                                                 // lights.go:18-28
+            V3 ld = mk(L.vec);
+            float ndotr = dot(ld, h.dnormal);
+            if (!(ndotr < 0.0f)) { need |= 1u << (1 + li); stage(1 + (int)li, ld, ra.p.step_size, cmul(albedo, scale(mk(L.color), ndotr * L.intensity))); }
+        } else {                                                                        // lights.go:38-54
+            V3 ld = normalize(sub(mk(L.vec), rayOrigin));
+            V3 toLight = sub(mk(L.vec), rayOrigin);
+            float distance = length(toLight);
+            toLight = normalize(toLight);
+            float ndotl = dot(h.dnormal, toLight);
+            if (!(ndotl <= 0.0f)) {
+                float att = 1.0f / (distance * distance);
+                need |= 1u << (1 + li); stage(1 + (int)li, ld, distance, cmul(albedo, scale(mk(L.color), ndotl * L.intensity * att)));
+            }
+        }
+    }
+    if (sc.nemissive > 0) {                                                             // :562-618
+        V3 eo = add(h.P, scale(h.dnormal, (float)0.01));
+        sh_eo = eo;
+        uint32_t choice = rng_intn(rng, sc.nemissive);
+        uint32_t et = sc.emissive[choice];
+        if (et >= sc.ntris) { err |= ERR_PRIM; et = 0; }
+        STri e = load_stri(sc, et);
+        if (e.mat >= sc.nmats) { err |= ERR_MAT; e.mat = 0; }
+        V3 lightPoint = sample_triangle_point(rng, e.A, e.B, e.C);
+        V3 lsn = interpolate_normal(lightPoint, e.A, e.B, e.C, e.N0, e.N1, e.N2);
+        V3 toLight = sub(lightPoint, eo);
+        float distance = length(toLight);
+        toLight = normalize(toLight);
+        float ndotl = dot(toLight, h.dnormal);
+        if (!(ndotl <= 0.0f)) {
+            V3 ec = mk(0, 0, 0);
+            float sndorl = -dot(toLight, lsn);
+            if (!(sndorl <= 0.0f)) {
+                float geometryTerm = ndotl * sndorl / (distance * distance);
+                float pdf = triangle_area(e.A, e.B, e.C);
+                pdf = 1.0f / (pdf * (float)sc.nemissive);
+                float pdf_brdf = dot(h.dnormal, toLight) / PT_PI32;
+                float pdf_sa = pdf * (distance * distance) / sndorl;
+                float weight = mis_weight(pdf_sa, pdf_brdf);
+                V3 le = mk(sc.mats[e.mat].ke);
+                V3 brdf = scale(albedo, (float)(1.0 / 3.14159265358979323846));
+                ec = scale(cmul(le, brdf), geometryTerm * weight / pdf);
+            }
+            need |= 1u << (1 + sc.nlights); stage(1 + (int)sc.nlights, toLight, distance - (float)0.01, ec);
+        }
+    }
+    return need;
+}
+
+// HandleDiffuseMaterial's final sum (:658-667): direct lighting (the free shadow rays' terms), ambient, the averaged
+// GI rays, and the emitter seen directly.
+__device__ __forceinline__ V3 diffuse_final(const DevScene &sc, const RenderArgs &ra, uint32_t fmat, int bounces, int bindex, V3 direct,
+                                            V3 gi_sum, V3 albedo) {
+    const PtMaterial &m = sc.mats[fmat];
+    V3 indirect = bounces > 0 ? gi_sum : mk(0, 0, 0);
+    V3 fin = direct;
+    fin = add(fin, scale(albedo, ra.p.ambient));
+    fin = add(fin, scale(indirect, 1.0f));
+    if (bindex == 0 && is_emissive(m)) fin = add(fin, mk(m.ke));
+    return fin;
+}
+// TraceRay's component sum (:218-223)
+__device__ __forceinline__ V3 combine_components(V3 diffuse, V3 reflective, V3 refr, float dg) {
+    float diffuseScale = 1.0f;
+    if (length(refr) > 0.0f) diffuseScale = (float)0.1;
+    V3 fin = add(add(add(scale(diffuse, diffuseScale), mk(0, 0, 0)), reflective), refr);
+    return scale(fin, dg);
+}
+// HandleReflectiveMaterial's result once its rays are in (:716-721), plus the refraction TraceRay adds to it (:165, :211)
+__device__ __forceinline__ V3 reflective_final(const DevScene &sc, const RenderArgs &ra, uint32_t fmat, V3 sum, V3 refr) {
+    const PtMaterial &m = sc.mats[fmat];
+    sum = scale(sum, 1.0f / (float)ra.p.scatter_rays);
+    sum = cmul(sum, mk(m.ks));
+    return add(sum, refr);
+}
+
+// The caller's direct lighting a queue entry carries: the contributions of the shadow rays connect found free, added in
+// the order of HandleDiffuseMaterial (sky sample :538-540, lights :557-559, emissive sample :617).  term(k) = (term.xyz,
+// bits(position of ray k in the shadow-ray queue)).
+template <typename Term>
+__device__ __forceinline__ V3 sum_free_terms(const Pool &pl, uint32_t &pneed, uint32_t &err, Term term) {
+    V3 pdirect = mk(0, 0, 0);
+    if (pneed >> pl.nshadow) { err |= ERR_PHASE; pneed = 0; }
+    for (int k = 0; k < pl.nshadow; ++k) {
+        if (!(pneed >> k & 1u)) continue;
+        const float4 v = term(k);
+        uint32_t qi = f2u(v.w);
+        if (qi >= pl.cap * (uint32_t)pl.nshadow) { err |= ERR_SLOT; qi = 0; }
+        if (pl.q_sray_occ[qi] == 0u) pdirect = add(pdirect, mk(v.x, v.y, v.z));
+    }
+    return pdirect;
+}
+// shadow term k of a record (words 19.. are not 16-byte aligned: four dword loads from a line the lane has just read)
+__device__ __forceinline__ float4 rec_term(const Pool &pl, const float4 *rec, int k) {
+    if (k >= pl.rec_inline) return rec[REC_BASE / 4 + (k - pl.rec_inline)];
+    const float *w = (const float *)rec + R_TERMS + 4 * k;
+    return make_float4(w[0], w[1], w[2], w[3]);
+}
+
 // States of the per-path machine inside one shade invocation.
 enum { ST_EXTENDED, ST_MATERIAL, ST_SHADOW_DONE, ST_GI_LOOP, ST_REFL_LOOP, ST_DIFFUSE_FINAL, ST_COMBINE, ST_RETURN };
 
@@ -467,78 +764,488 @@ enum { SRW = 7 };
 __device__ __forceinline__ int stage_word(int k) { return k == 0 ? 0 : SRW * k - 1; }
 constexpr float SKY_RAY_RANGE = 100000.0f;
 
-// Reads the extend queue just traced (entries 0 .. n_ext-1 of buffer `cur`: ray, pending-call state, extend's answer, the
-// parent's shadow terms, all coalesced) and the shadow-wait queue (n_shp parked frames whose shadow rays connect has
-// answered); writes the next buffers.  The grid covers a full pool; workgroups beyond this iteration's work leave.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, int cur,
-                                                                                               unsigned long long *counters) {
-    const uint32_t na = pl.it->n_ext, nb = pl.it->n_shp;
-    if (blockIdx.x * blockDim.x >= na + nb) return;
-    __shared__ __align__(16) float s_fw[FRW * 256];
-    extern __shared__ float s_ray[];           // (SRW * nshadow - 1) * 256 floats
-    const float4 *list_a = pl.q_ext_ray[cur], *list_a_arg = pl.q_ext_arg[cur], *list_a_sh = pl.q_ext_sh[cur];
-    const float4 *list_b = pl.q_shpath[cur], *list_b_sh = pl.q_shp_sh[cur];
-    float4 *q_ray_next = pl.q_ext_ray[cur ^ 1], *q_arg_next = pl.q_ext_arg[cur ^ 1], *q_ext_sh_next = pl.q_ext_sh[cur ^ 1];
-    float4 *q_shpath_next = pl.q_shpath[cur ^ 1], *q_shp_sh_next = pl.q_shp_sh[cur ^ 1];
-    unsigned long long *qc_ext_next = pl.qcnt + (size_t)(QC_EXT0 + (cur ^ 1)) * QC_STRIDE;
-    unsigned long long *qc_shp_next = pl.qcnt + (size_t)(QC_SHP0 + (cur ^ 1)) * QC_STRIDE;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < na + nb;
+// ---- queue bookkeeping shared by the shade kernels ---------------------------------------------------------------
+// One atomic per workgroup and queue: ballot + popcount per wave, the four waves summed in LDS.  Queues: 0 extend,
+// 1 shadow-wait (lean), 2 shadow-wait (general, filled from the back), 3 free list, 4.. the NSB shadow-ray buckets.
+enum { BK_EXT = 0, BK_SHP = 1, BK_SHA = 2, BK_FREE = 3, BK_RAY = 4, BK_N = BK_RAY + NSB };
+struct TailOut {              // what one path leaves a shade kernel with
+    bool want_extend = false, want_shadow = false, finished = false, anc = false;
+    uint32_t need_out = 0;    // kinds of the shadow rays it staged
     uint32_t slot = 0;
-    bool want_extend = false, want_shadow = false, finished = false;
-    uint32_t n_sray = 0;                       // shadow rays this path wants to enqueue
-    uint32_t need_out = 0;                     // their kinds (bit k = shadow ray kind k)
-    uint32_t diffuse_events = 0;
-    V3 out_o = mk(0, 0, 0), out_d = mk(0, 0, 0);   // the ray of a path that wants an extend (goes into its queue entry)
-    float4 out_a0 = make_float4(0, 0, 0, 0), out_a1 = out_a0, out_a2 = out_a0;   // ... and its pending-call state
-    V3 sh_o = mk(0, 0, 0), sh_eo = mk(0, 0, 0);    // origins of the staged shadow rays (sky / light rays; emissive sample)
-    float4 *store_to = nullptr;                    // where the top frame (still in LDS) is parked when the path leaves
-    if (live) {
-        const bool pending = i < na;                                        // the extend list holds exactly the pending calls
-        float4 qa = make_float4(0, 0, 0, 0), qb = qa, a0, a1 = qa, a2, hq = qa;
-        uint32_t pneed = 0;                                                 // shadow terms that arrive with this entry
-        const float4 *pterms;
-        if (pending) {
-            qa = list_a[2 * (size_t)i]; qb = list_a[2 * (size_t)i + 1];
-            a0 = list_a_arg[QA * (size_t)i]; a1 = list_a_arg[QA * (size_t)i + 1]; a2 = list_a_arg[QA * (size_t)i + 2];
-            hq = pl.q_ext_hit[i];
-            slot = f2u(qa.w);
-            pneed = f2u(a1.z) >> 8;
-            pterms = list_a_sh + (size_t)i * pl.nshadow;
-        } else {
-            const float4 e0 = list_b[2 * (size_t)(i - na)], e1 = list_b[2 * (size_t)(i - na) + 1];
-            slot = f2u(e0.x);
-            a0 = make_float4(e0.y, e0.z, e0.w, e1.x);
-            a2 = make_float4(0.0f, 0.0f, 0.0f, e1.y);
-            pneed = f2u(e1.z);
-            pterms = list_b_sh + (size_t)(i - na) * pl.nshadow;
+};
+struct TailPos {              // where its entries go
+    uint32_t ext = 0, shp = 0, fin = 0;
+    bool shp_back = false;
+    uint32_t ray[NSB - 1] = {};   // position in bucket b of its ray of kind b
+    uint32_t ray_last = 0;        // first position in the shared last bucket
+};
+// sq: LDS words [BK_N][4] (as float bit patterns: one access type per LDS word); the workgroup's waves must all call.
+__device__ __forceinline__ TailPos tail_reserve(const Pool &pl, int cur, float *sq, const TailOut &o, uint32_t diffuse_events,
+                                                unsigned long long *counters) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const bool shp_lean = o.want_shadow && !o.anc, shp_anc = o.want_shadow && o.anc;
+    const unsigned long long m_ext = __ballot(o.want_extend), m_shp = __ballot(shp_lean), m_sha = __ballot(shp_anc), m_fin = __ballot(o.finished);
+    // shadow rays by bucket: kinds 0 .. NSB-2 are one ray per lane at most (ballot), the last bucket can take several
+    const uint32_t last_bits = o.need_out >> (NSB - 1);
+    uint32_t incl = (uint32_t)__popc(last_bits);
+    if (pl.nshadow >= NSB) {
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
         }
+    }
+    unsigned long long m_ray[NSB - 1];
+#pragma unroll
+    for (int b = 0; b < NSB - 1; ++b) m_ray[b] = __ballot((o.need_out >> b) & 1u);
+    for (int off = 32; off > 0; off >>= 1) diffuse_events += __shfl_xor(diffuse_events, off);
+#define SQ(q, w) f2u(sq[(q) * 4 + (w)])
+#define SQ_SET(q, w, v) (sq[(q) * 4 + (w)] = u2f(v))
+    if (lane == 63) {
+        SQ_SET(BK_EXT, wv, (uint32_t)__popcll(m_ext)); SQ_SET(BK_SHP, wv, (uint32_t)__popcll(m_shp)); SQ_SET(BK_SHA, wv, (uint32_t)__popcll(m_sha));
+        SQ_SET(BK_FREE, wv, (uint32_t)__popcll(m_fin));
+#pragma unroll
+        for (int b = 0; b < NSB - 1; ++b) SQ_SET(BK_RAY + b, wv, (uint32_t)__popcll(m_ray[b]));
+        SQ_SET(BK_RAY + NSB - 1, wv, pl.nshadow >= NSB ? incl : 0u);
+    }
+    lds_barrier();
+    if (threadIdx.x < BK_N) {
+        const int q = threadIdx.x;
+        const uint32_t c0 = SQ(q, 0), c1 = SQ(q, 1), c2 = SQ(q, 2), c3 = SQ(q, 3);
+        const uint32_t total = c0 + c1 + c2 + c3;
+        const int nxt = cur ^ 1;
+        const int w = q == BK_EXT ? QC_EXT0 + nxt : q == BK_SHP ? QC_SHP0 + nxt : q == BK_SHA ? QC_SHA0 + nxt : q == BK_FREE ? QC_FREE : QC_SRAY + (q - BK_RAY);
+        uint32_t base = 0;
+        if (total) base = (uint32_t)atomicAdd(&pl.qcnt[(size_t)w * QC_STRIDE], (unsigned long long)total);
+        SQ_SET(q, 0, base); SQ_SET(q, 1, base + c0); SQ_SET(q, 2, base + c0 + c1); SQ_SET(q, 3, base + c0 + c1 + c2);
+        if (q == BK_FREE && total) atomicAdd(&counter_shard(counters)[CNT_SAMPLES], (unsigned long long)total);
+    }
+    if (lane == 0 && diffuse_events) atomicAdd(&counter_shard(counters)[CNT_DIFFUSE], (unsigned long long)diffuse_events);
+    lds_barrier();
+    TailPos p;
+    p.ext = SQ(BK_EXT, wv) + (uint32_t)__popcll(m_ext & lt);
+    p.shp_back = shp_anc;
+    p.shp = shp_anc ? SQ(BK_SHA, wv) + (uint32_t)__popcll(m_sha & lt) : SQ(BK_SHP, wv) + (uint32_t)__popcll(m_shp & lt);
+    p.fin = SQ(BK_FREE, wv) + (uint32_t)__popcll(m_fin & lt);
+#pragma unroll
+    for (int b = 0; b < NSB - 1; ++b) p.ray[b] = SQ(BK_RAY + b, wv) + (uint32_t)__popcll(m_ray[b] & lt);
+    p.ray_last = SQ(BK_RAY + NSB - 1, wv) + (incl - (uint32_t)__popc(last_bits));
+#undef SQ
+#undef SQ_SET
+    return p;
+}
+// entry of the shadow-wait queue at position `pos` of its side (lean from the front, general from the back)
+__device__ __forceinline__ size_t shp_entry(const Pool &pl, uint32_t pos, bool back) { return back ? (size_t)pl.cap - 1 - pos : (size_t)pos; }
+
+// Writes a path's staged shadow rays into their buckets and hands back the term (contribution, queue position) of each
+// through put(k, term).  s_ray = the staging area ([word][thread] columns of 256), tid = this thread's column.
+template <typename Put>
+__device__ __forceinline__ void flush_shadow_rays(const Pool &pl, const float *s_ray, uint32_t need_out, const TailPos &tp, V3 sh_o, V3 sh_eo, Put put) {
+    uint32_t pos_last = tp.ray_last;
+    for (int k = 0; k < pl.nshadow; ++k) {
+        if (!(need_out >> k & 1u)) continue;
+        uint32_t pos;
+        if (k < NSB - 1) {
+            pos = 0;
+#pragma unroll
+            for (int b = 0; b < NSB - 1; ++b) if (b == k) pos = tp.ray[b];
+        } else {
+            pos = pos_last++;
+        }
+        const int b = k < NSB - 1 ? k : NSB - 1;
+        const size_t qi = (size_t)b * pl.cap + pos;
+        const V3 o = k == pl.nshadow - 1 ? sh_eo : sh_o;            // the emissive sample starts from its own offset (:563)
+        const float *sr = s_ray + (size_t)stage_word(k) * 256 + threadIdx.x;
+        pl.q_sray_a[qi] = make_float4(o.x, o.y, o.z, k ? sr[1536] : SKY_RAY_RANGE);
+        pl.q_sray_b[qi] = make_float4(sr[0], sr[256], sr[512], 0.0f);
+        put(k, make_float4(sr[768], sr[1024], sr[1280], u2f((uint32_t)qi)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------ shade: returning calls
+// List L_RET -- calls that return without shading a hit: the entry test failed (tracer.go:16), the march ended in the
+// horizon (:253-255) or in nothing (:260-263: the sky) -- and the lean side of the shadow-wait queue: frames parked
+// for their shadow rays (bounces <= 0, so HandleDiffuseMaterial goes straight to its final sum).  With scatterRays == 1
+// and no refraction frame below (the host and classify() route everything else to the general kernel) such a path
+// unwinds all the way to its primary sample: every frame it returns to is waiting for its only GI or reflection ray
+// (:640-647, :715-721), finishes, and returns in turn.  Per level: one 128-byte frame line read, a dozen additions.
+// No LDS frame, no staging area: the kernel runs at full occupancy.
+__global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, RenderArgs ra, int cur, unsigned long long *counters) {
+    const uint32_t na = (uint32_t)pl.qcnt[(size_t)(QC_LIST + L_RET) * QC_STRIDE], nb = pl.it->n_shp;
+    const uint32_t na_pad = (na + 63u) & ~63u;                  // the parked frames start on a wave boundary
+    if (blockIdx.x * blockDim.x >= na_pad + nb) return;
+    __shared__ float s_q[BK_N * 4];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool pending = i < na, parked = i >= na_pad && i - na_pad < nb;
+    TailOut to;
+    uint32_t diffuse_events = 0;
+    if (pending || parked) {
+        uint32_t err = 0, sid = 0, slot = 0;
+        int depth = 0;
+        V3 ret = mk(0, 0, 0), pd = mk(0, 0, 0);
+        auto frame_at = [&](int dep) -> const float4 * { return pl.fr + ((size_t)slot * pl.nframes + dep) * 8; };
+        if (pending) {
+            uint32_t e = pl.q_idx[(size_t)L_RET * pl.cap + i];
+            if (e >= pl.it->n_ext) { err |= ERR_QUEUE; e = 0; }
+            const float4 *rec = rec_at(pl, cur, e);
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+            slot = f2u(r0.w) & (uint32_t)SLOT_MASK;
+            const uint32_t ctx = f2u(r0.w) >> CTX_SHIFT;
+            sid = f2u(r1.w);
+            const uint32_t status = f2u(r2.x) >> 30;
+            depth = (int)(f2u(r3.x) & 0xFFu);
+            uint32_t pneed = f2u(r3.y) >> 8;
+            if (slot >= pl.cap) { err |= ERR_SLOT; slot = 0; }
+            if (depth >= pl.nframes) { err |= ERR_DEPTH; depth = 0; }
+            pd = sum_free_terms(pl, pneed, err, [&](int k) { return rec_term(pl, rec, k); });
+            if (status == (uint32_t)HS_HIT && !(ctx & CTX_FAIL)) err |= ERR_CLASS;          // a hit to shade does not belong here
+            if (!(ctx & CTX_FAIL) && status == (uint32_t)HS_MISS && sc.sky.kind != PTMI_SKY_NONE)
+                ret = sky_sample(sc.sky, sc.sky_img, mk(r1.x, r1.y, r1.z));                 // :260-263
+        } else {
+            const size_t k = i - na_pad;
+            const float4 e0 = pl.q_shpath[cur][2 * k], e1 = pl.q_shpath[cur][2 * k + 1];
+            slot = f2u(e0.x); sid = f2u(e0.y);
+            depth = (int)(f2u(e1.x) & 0xFFu);
+            uint32_t pneed = f2u(e1.z);
+            if (slot >= pl.cap) { err |= ERR_SLOT; slot = 0; }
+            if (depth >= pl.nframes) { err |= ERR_DEPTH; depth = 0; }
+            const float4 *terms = pl.q_shp_sh[cur] + k * (size_t)pl.nshadow;
+            const V3 direct = sum_free_terms(pl, pneed, err, [&](int t) { return terms[t]; });
+            // the parked frame: HandleDiffuseMaterial's final sum with no GI rays (bounces <= 0), then TraceRay's (:218-223)
+            const float4 *f = frame_at(depth);
+            const float4 f0 = f[0], f3 = f[3], f4 = f[4], f5 = f[5], f6 = f[6], f7 = f[7];
+            const uint32_t bb = f2u(f0.x), sp = f2u(f0.y);
+            uint32_t fmat = f2u(f0.z);
+            if (fmat >= sc.nmats) { err |= ERR_MAT; fmat = 0; }
+            const int bounces = (int)(int16_t)(bb & 0xFFFFu), bindex = (int)((bb >> 16) & 0xFFu);
+            if ((sp >> 24) != (uint32_t)PH_SHADOW_WAIT) err |= ERR_PHASE;
+            if (bounces > 0) err |= ERR_CLASS;
+            const V3 refr = mk(f4.w, f5.x, f5.y), albedo = mk(f5.z, f5.w, f6.x), gi = mk(f6.y, f6.z, f6.w);
+            const V3 fin = diffuse_final(sc, ra, fmat, bounces, bindex, direct, gi, albedo);
+            diffuse_events++;
+            ret = combine_components(fin, mk(0, 0, 0), refr, f3.w);
+            pd = mk(f7.x, f7.y, f7.z);
+        }
+        // unwind: hand `ret` to the caller frame, and with it the caller's direct lighting this call carried
+        while (depth > 0 && !err) {
+            depth--;
+            const float4 *f = frame_at(depth);
+            const float4 f0 = f[0], f3 = f[3], f4 = f[4], f5 = f[5], f6 = f[6], f7 = f[7];
+            const uint32_t bb = f2u(f0.x), sp = f2u(f0.y);
+            uint32_t fmat = f2u(f0.z);
+            if (fmat >= sc.nmats) { err |= ERR_MAT; fmat = 0; }
+            const int bounces = (int)(int16_t)(bb & 0xFFFFu), bindex = (int)((bb >> 16) & 0xFFu);
+            const uint32_t ph = sp >> 24, s = sp & 0xFFFFFFu;
+            const float dg = f3.w;
+            V3 fdiff = mk(f4.x, f4.y, f4.z);
+            const V3 refr = mk(f4.w, f5.x, f5.y), albedo = mk(f5.z, f5.w, f6.x);
+            V3 fsum = mk(f6.y, f6.z, f6.w);
+            if (s != 0u) err |= ERR_CLASS;                                  // scatterRays == 1: the frame waits for its only ray
+            if (ph == (uint32_t)PH_GI_WAIT) {                               // :640-647, :658-667
+                fdiff = pd;                                                 // the first scattered ray carried this frame's shadow terms
+                fsum = add(fsum, cmul(ret, albedo));
+                fsum = scale(fsum, 1.0f / (float)ra.p.scatter_rays);
+                const V3 fin = diffuse_final(sc, ra, fmat, bounces, bindex, fdiff, fsum, albedo);
+                diffuse_events++;
+                ret = combine_components(fin, mk(0, 0, 0), refr, dg);
+            } else if (ph == (uint32_t)PH_REFL_WAIT) {                      // :715-721
+                fsum = add(fsum, ret);
+                ret = combine_components(fdiff, reflective_final(sc, ra, fmat, fsum, refr), refr, dg);
+            } else {
+                err |= ERR_PHASE;
+            }
+            pd = mk(f7.x, f7.y, f7.z);
+        }
+        if (err) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)err); ret = mk(0, 0, 0); }
+        float *o = pl.out + 3 * (size_t)(sid < ra.total ? sid : 0);
+        o[0] = ret.x; o[1] = ret.y; o[2] = ret.z;
+        to.finished = true; to.slot = slot;
+    }
+    const TailPos tp = tail_reserve(pl, cur, s_q, to, diffuse_events, counters);
+    if (to.finished) pl.q_free[tp.fin] = to.slot;
+}
+
+// ------------------------------------------------------------------------------------------ shade: fresh diffuse hits
+// List L_DIFF -- a pending call whose ray hit a plain diffuse surface (no glass, no accretion disk, reflectivity < 0.1,
+// not an emitter seen by an indirect ray): the entry of TraceRay (:36-48), HandleDiffuseMaterial's direct lighting
+// (:523-618) and its first GI ray (:620-647), or, with no bounces left, the wait for the shadow rays.  Straight-line
+// code: the frame is put together in registers and parked, the child (or the shadow-wait entry) goes into its queue.
+// LDS: the staged shadow rays ([word][thread], as in the general kernel), reused as the exchange area of the whole-line
+// stores once the rays are out: 16 words per thread at least, 20 with three shadow-ray kinds -- four workgroups per CU
+// and more where the general kernel has three.
+enum { XCH_WORDS = 16 };
+// Half a line per lane through a [16][256] exchange area: lane 8 g + 4 r + q writes quarter q of the half-lines of lanes
+// 8 g + r, 8 g + 2 + r, ... (every store instruction covers sixteen 64-byte sectors).  The lane's 16 words of this half
+// are in its column already.
+__device__ __forceinline__ void wave_store_half(const float *col, float4 *dst, int half) {
+    const unsigned long long m_st = __ballot(dst != nullptr);
+    if (!m_st) return;
+    const int lane = threadIdx.x & 63, grp = lane & ~7, r = (lane >> 2) & 1, q = lane & 3;
+    const uint32_t lo = (uint32_t)(uintptr_t)dst, hi = (uint32_t)((uintptr_t)dst >> 32);
+    const float *base = col - lane;
+    for (int i = 0; i < 4; ++i) {
+        const int src = grp + 2 * i + r;
+        const uint32_t slo = (uint32_t)__shfl((int)lo, src), shi = (uint32_t)__shfl((int)hi, src);
+        if (m_st >> src & 1ull) {
+            float4 *d = (float4 *)(((uintptr_t)shi << 32) | (uintptr_t)slo);
+            const float *c = base + src;
+            d[4 * half + q] = make_float4(c[(4 * q) * 256], c[(4 * q + 1) * 256], c[(4 * q + 2) * 256], c[(4 * q + 3) * 256]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void shade_diff_kernel(Pool pl, DevScene sc, RenderArgs ra, int cur, unsigned long long *counters) {
+    const uint32_t n = (uint32_t)pl.qcnt[(size_t)(QC_LIST + L_DIFF) * QC_STRIDE];
+    if (blockIdx.x * blockDim.x >= n) return;
+    __shared__ float s_q[BK_N * 4];
+    extern __shared__ float s_ray[];           // max(SRW * nshadow - 1, XCH_WORDS) * 256 floats
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    TailOut to;
+    V3 sh_o = mk(0, 0, 0), sh_eo = mk(0, 0, 0);
+    float fw[32];                              // the frame this visit parks (F_*), word 31 unused
+    float rw[20];                              // the child's record, words 0 .. 18 (its terms follow from the staged rays)
+#pragma unroll
+    for (int k = 0; k < 32; ++k) fw[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 20; ++k) rw[k] = 0.0f;
+    float4 *frame_dst = nullptr;
+    uint32_t sid = 0, depth_trk = 0, rng_key = 0, rng_ctr = 0;
+    float trk0 = 1.0f;
+    if (i < n) {
         uint32_t err = 0;
-        if (slot >= pl.cap) { err = ERR_SLOT; slot = 0; }
-        const uint32_t sid = f2u(a0.x);
-        Rng rng; rng.key = f2u(a0.y); rng.ctr = f2u(a0.z);
-        const uint32_t packed = f2u(a0.w);
+        uint32_t e = pl.q_idx[(size_t)L_DIFF * pl.cap + i];
+        if (e >= pl.it->n_ext) { err |= ERR_QUEUE; e = 0; }
+        const float4 *rec = rec_at(pl, cur, e);
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+        uint32_t slot = f2u(r0.w) & (uint32_t)SLOT_MASK;
+        if (slot >= pl.cap) { err |= ERR_SLOT; slot = 0; }
+        sid = f2u(r1.w);
+        Rng rng; rng.key = f2u(r2.z); rng.ctr = f2u(r2.w);
+        const uint32_t hitword = f2u(r2.x), packed = f2u(r3.x), fword = f2u(r3.y);
         int depth = (int)(packed & 0xFFu);
         if (depth >= pl.nframes) { err |= ERR_DEPTH; depth = 0; }
         uint32_t trk_len = (packed >> 8) & 0xFFu;
         if ((int)trk_len > pl.ntrk) { err |= ERR_DEPTH; trk_len = 0; }
-        float trk0 = a2.w;
-        const int hs = f2i(hq.x), hprim = f2i(hq.y);
-        const float ht = hq.z, vt0 = qb.w, vt1 = hq.w;
+        const int bounces = (int)(int8_t)((packed >> 16) & 0xFFu), bindex = (int)(packed >> 24);
+        const uint32_t flags = fword & 0xFFu & ~(uint32_t)FL_FLIPPED;
+        uint32_t pneed = fword >> 8;
+        const float energy = r3.z;
+        trk0 = r3.w;
+        const V3 ln = mk(r4.x, r4.y, r4.z);
+        const V3 pdirect = sum_free_terms(pl, pneed, err, [&](int k) { return rec_term(pl, rec, k); });
+        if ((hitword >> 30) != (uint32_t)HS_HIT || bounces < 0 || energy < (float)1e-2) err |= ERR_CLASS;
+        const int hprim = (int)(hitword & 0x3FFFFFFFu);
+        const V3 cur_o = mk(r0.x, r0.y, r0.z), cur_d = mk(r1.x, r1.y, r1.z);
+        // ---- TraceRay :36-48, :93-113 (no disk), :49-91 (no glass), :116-118 (reflectivity < 0.1: HandleDiffuseMaterial)
+        Hit h;
+        derive_hit(sc, cur_o, cur_d, r2.y, hprim, false, h, err);
+        const PtMaterial &m = sc.mats[h.mat];
+        const float reflectivity = (m.ks[0] + m.ks[1] + m.ks[2]) / 3.0f;
+        if ((m.flags & PTMI_MAT_GLASS) || ((m.flags & PTMI_MAT_ACCRETION) && sc.has_bh) || !(reflectivity < (float)0.1) ||
+            (bindex > 0 && is_emissive(m)))
+            err |= ERR_CLASS;
+        // ---- HandleDiffuseMaterial :523-618
+        const uint32_t need = direct_lighting(sc, ra, h, rng, sh_o, sh_eo, err, [&](int k, V3 d, float range, V3 term) {
+            float *sr = s_ray + (size_t)stage_word(k) * 256 + tid;
+            sr[0] = d.x; sr[256] = d.y; sr[512] = d.z;
+            sr[768] = term.x; sr[1024] = term.y; sr[1280] = term.z;
+            if (k) sr[1536] = range;
+        });
+        uint32_t phase;
+        if (bounces > 0) {                                                              // :622-647: the first (s = 0) GI ray
+            V3 t1, t2; tangent_frame(h.dnormal, t1, t2);
+            const V3 dir = cosine_sample2(rng, h.dnormal, t1, t2);
+            const V3 co = add(h.P, scale(h.dnormal, (float)0.001));
+            phase = PH_GI_WAIT;
+            // the child: TraceRay(bounces-1, bounceIndex+1, lastSurfaceNormal = normal, not specular, the frame's energy)
+            const uint32_t cflags = flags & (uint32_t)FL_ANC;
+            rw[R_O] = co.x; rw[R_O + 1] = co.y; rw[R_O + 2] = co.z;
+            rw[R_SLOT] = u2f(slot | call_ctx(bounces - 1, bindex + 1, energy, cflags) << CTX_SHIFT);
+            rw[R_D] = dir.x; rw[R_D + 1] = dir.y; rw[R_D + 2] = dir.z;
+            rw[R_SID] = u2f(sid);
+            rw[R_KEY] = u2f(rng.key); rw[R_CTR] = u2f(rng.ctr);
+            rw[R_PACK] = u2f(pack_call(depth + 1, trk_len, bounces - 1, bindex + 1));
+            rw[R_FLAGS] = u2f(cflags | need << 8);
+            rw[R_ENERGY] = energy; rw[R_TRK0] = trk0;
+            rw[R_LN] = h.dnormal.x; rw[R_LN + 1] = h.dnormal.y; rw[R_LN + 2] = h.dnormal.z;
+            to.want_extend = true;
+        } else {
+            phase = PH_SHADOW_WAIT;
+            if (!need) err |= ERR_CLASS;            // no ray to wait for: the general kernel's case (no sky, no light reaches, no emitter)
+            to.want_shadow = true;
+        }
+        to.anc = (flags & FL_ANC) != 0 || ra.p.scatter_rays != 1;     // who unwinds a parked frame: shade_ret_kernel or the general kernel
+        to.need_out = need;
+        to.slot = slot;
+        depth_trk = (uint32_t)depth | trk_len << 8;
+        rng_key = rng.key; rng_ctr = rng.ctr;
+        // ---- the frame (F_*)
+        fw[F_BB] = u2f(((uint32_t)bounces & 0xFFFFu) | ((uint32_t)bindex & 0xFFu) << 16 | flags << 24);
+        fw[F_SP] = u2f(phase << 24);
+        fw[F_MAT] = u2f(h.mat); fw[F_ENERGY] = energy;
+        fw[F_LN] = ln.x; fw[F_LN + 1] = ln.y; fw[F_LN + 2] = ln.z;
+        fw[F_RO] = cur_o.x; fw[F_RO + 1] = cur_o.y; fw[F_RO + 2] = cur_o.z;
+        fw[F_RD] = cur_d.x; fw[F_RD + 1] = cur_d.y; fw[F_RD + 2] = cur_d.z;
+        fw[F_T] = r2.y; fw[F_PRIM] = i2f(h.prim);
+        fw[F_DG] = 1.0f;
+        fw[F_ALBEDO] = h.albedo.x; fw[F_ALBEDO + 1] = h.albedo.y; fw[F_ALBEDO + 2] = h.albedo.z;
+        fw[F_PDIRECT] = pdirect.x; fw[F_PDIRECT + 1] = pdirect.y; fw[F_PDIRECT + 2] = pdirect.z;
+        frame_dst = pl.fr + ((size_t)slot * pl.nframes + depth) * 8;
+        if (err) {          // self-check failed: report, drop the path with zero radiance
+            atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)err);
+            float *o = pl.out + 3 * (size_t)(sid < ra.total ? sid : 0);
+            o[0] = o[1] = o[2] = 0.0f;
+            to.want_extend = to.want_shadow = false; to.need_out = 0; to.finished = true; frame_dst = nullptr;
+        }
+    }
+    const TailPos tp = tail_reserve(pl, cur, s_q, to, 0u, counters);
+    // shadow rays out of the staging area; their terms into the child's record (first rec_inline of them: registers,
+    // stored with the record's lines) or beside the shadow-wait entry
+    float4 *rec_dst = to.want_extend ? rec_at(pl, cur ^ 1, tp.ext) : nullptr;
+    float tw[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) tw[k] = 0.0f;
+    float4 *shp_terms = nullptr;
+    if (to.want_shadow) {
+        const size_t ps = shp_entry(pl, tp.shp, tp.shp_back);
+        pl.q_shpath[cur ^ 1][2 * ps] = make_float4(u2f(to.slot), u2f(sid), u2f(rng_key), u2f(rng_ctr));
+        pl.q_shpath[cur ^ 1][2 * ps + 1] = make_float4(u2f(depth_trk), trk0, u2f(to.need_out), u2f(to.anc ? (uint32_t)FL_ANC : 0u));
+        shp_terms = pl.q_shp_sh[cur ^ 1] + ps * (size_t)pl.nshadow;
+    }
+    if (to.finished) pl.q_free[tp.fin] = to.slot;
+    if (to.need_out) {
+        const int ninl = pl.rec_inline;
+        flush_shadow_rays(pl, s_ray, to.need_out, tp, sh_o, sh_eo, [&](int k, float4 term) {
+            if (shp_terms) { shp_terms[k] = term; return; }
+            if (k >= ninl) { rec_dst[REC_BASE / 4 + (k - ninl)] = term; return; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j == k) { tw[4 * j] = term.x; tw[4 * j + 1] = term.y; tw[4 * j + 2] = term.z; tw[4 * j + 3] = term.w; }
+        });
+    }
+    // whole-line stores: the parked frame and the child's record, each in two halves through the exchange area (the
+    // staged rays are out; every lane only touches its own wave's columns)
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float *col = s_ray + tid;
+    auto store_line = [&](float4 *dst, auto word) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) col[k * 256] = word(16 * half + k);
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wave_store_half(col, dst, half);
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+    store_line(frame_dst, [&](int k) { return fw[k]; });
+    store_line(rec_dst, [&](int k) { return k < R_TERMS ? rw[k] : (k < R_TERMS + 12 ? tw[k - R_TERMS] : 0.0f); });
+}
+
+// ------------------------------------------------------------------------------------------ shade: the general kernel
+// Every other class, one list each, laid end to end with each list padded to whole waves (a wave then holds one class:
+// non-hits that unwind through refraction frames or scatterRays > 1, glass, reflective, mid-reflective, emitters hit by
+// indirect rays, diffuse hits the lean kernel does not take, the accretion disk), then the general side of the
+// shadow-wait queue.  Reads each entry's record (gathered), writes the next buffers.  The grid covers a full pool;
+// workgroups beyond this iteration's work leave.
+struct GenLists { uint32_t n[N_GEN]; };
+__device__ __forceinline__ GenLists gen_lists(const Pool &pl) {
+    GenLists g;
+#pragma unroll
+    for (int l = 0; l < N_GEN; ++l) g.n[l] = (uint32_t)pl.qcnt[(size_t)(QC_LIST + L_GEN + l) * QC_STRIDE];
+    return g;
+}
+__device__ __forceinline__ uint32_t gen_padded_total(const GenLists &g) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int l = 0; l < N_GEN; ++l) t += (g.n[l] + 63u) & ~63u;
+    return t;
+}
+// thread i of the general kernel -> (list, position); false: a padding lane
+__device__ __forceinline__ bool gen_entry(const GenLists &g, uint32_t i, int &list, uint32_t &pos) {
+    uint32_t rem = i;
+    int l = 0;
+#pragma unroll
+    for (int q = 0; q < N_GEN - 1; ++q) {
+        const uint32_t pad = (g.n[q] + 63u) & ~63u;
+        if (l == q && rem >= pad) { rem -= pad; l = q + 1; }
+    }
+    list = L_GEN + l; pos = rem;
+    return rem < g.n[l];
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void shade_kernel(Pool pl, DevScene sc, RenderArgs ra, int cur,
+                                                                                               unsigned long long *counters) {
+    const GenLists gl = gen_lists(pl);
+    const uint32_t na = gen_padded_total(gl), nb = pl.it->n_sha;
+    if (blockIdx.x * blockDim.x >= na + nb) return;
+    __shared__ __align__(16) float s_fw[FRW * 256];
+    extern __shared__ float s_ray[];           // (SRW * nshadow - 1) * 256 floats
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int my_list = 0; uint32_t my_pos = 0;
+    const bool pending = i < na && gen_entry(gl, i, my_list, my_pos);
+    const bool live = pending || (i >= na && i - na < nb);
+    uint32_t slot = 0;
+    bool want_extend = false, want_shadow = false, finished = false, anc_out = false;
+    uint32_t n_sray = 0;                       // shadow rays this path wants to enqueue
+    uint32_t need_out = 0;                     // their kinds (bit k = shadow ray kind k)
+    uint32_t diffuse_events = 0;
+    V3 out_o = mk(0, 0, 0), out_d = mk(0, 0, 0);   // the ray of a path that wants an extend (goes into its queue entry)
+    uint32_t out_sid = 0, out_key = 0, out_ctr = 0, out_pack = 0, out_flags = 0, out_ctx = 0, out_depth_trk = 0;
+    float out_energy = 0.0f, out_trk0 = 1.0f;
+    V3 out_ln = mk(0, 0, 0);
+    V3 sh_o = mk(0, 0, 0), sh_eo = mk(0, 0, 0);    // origins of the staged shadow rays (sky / light rays; emissive sample)
+    float4 *store_to = nullptr;                    // where the top frame (still in LDS) is parked when the path leaves
+    if (live) {
+        float4 qa = make_float4(0, 0, 0, 0), qb = qa;
+        uint32_t pneed = 0;                                                 // shadow terms that arrive with this entry
+        uint32_t err = 0;
+        uint32_t sid, packed, in_flags = 0;
+        Rng rng;
+        float trk0, in_energy = 0.0f, ht = 0.0f, vt0 = 1.0f, vt1 = 1.0f;
+        int hs = HS_MISS, hprim = -1, in_bounces = 0, in_bindex = 0;
+        V3 in_ln = mk(0, 0, 0);
+        V3 pdirect;
+        if (pending) {
+            uint32_t e = pl.q_idx[(size_t)my_list * pl.cap + my_pos];
+            if (e >= pl.it->n_ext) { err |= ERR_QUEUE; e = 0; }
+            const float4 *rec = rec_at(pl, cur, e);
+            qa = rec[0]; qb = rec[1];
+            const float4 r2 = rec[2], r3 = rec[3], r4 = rec[4];
+            slot = f2u(qa.w) & (uint32_t)SLOT_MASK;
+            sid = f2u(qb.w);
+            const uint32_t hitword = f2u(r2.x);
+            hs = (int)(hitword >> 30);
+            hprim = hs == HS_HIT ? (int)(hitword & 0x3FFFFFFFu) : -1;
+            ht = r2.y;
+            rng.key = f2u(r2.z); rng.ctr = f2u(r2.w);
+            packed = f2u(r3.x);
+            in_bounces = (int)(int8_t)((packed >> 16) & 0xFFu); in_bindex = (int)(packed >> 24);
+            in_flags = f2u(r3.y) & 0xFFu;
+            pneed = f2u(r3.y) >> 8;
+            in_energy = r3.z; trk0 = r3.w;
+            in_ln = mk(r4.x, r4.y, r4.z);
+            if (sc.has_bh) { const float2 v = ((const float2 *)rec)[R_VT / 2]; vt1 = v.x; vt0 = v.y; }
+            if (slot >= pl.cap) { err |= ERR_SLOT; slot = 0; }
+            pdirect = sum_free_terms(pl, pneed, err, [&](int k) { return rec_term(pl, rec, k); });
+        } else {
+            const size_t k = shp_entry(pl, i - na, true);
+            const float4 e0 = pl.q_shpath[cur][2 * k], e1 = pl.q_shpath[cur][2 * k + 1];
+            slot = f2u(e0.x);
+            sid = f2u(e0.y); rng.key = f2u(e0.z); rng.ctr = f2u(e0.w);
+            packed = f2u(e1.x);
+            trk0 = e1.y;
+            pneed = f2u(e1.z);
+            if (slot >= pl.cap) { err |= ERR_SLOT; slot = 0; }
+            const float4 *terms = pl.q_shp_sh[cur] + k * (size_t)pl.nshadow;
+            pdirect = sum_free_terms(pl, pneed, err, [&](int t) { return terms[t]; });
+        }
+        int depth = (int)(packed & 0xFFu);
+        if (depth >= pl.nframes) { err |= ERR_DEPTH; depth = 0; }
+        uint32_t trk_len = (packed >> 8) & 0xFFu;
+        if ((int)trk_len > pl.ntrk) { err |= ERR_DEPTH; trk_len = 0; }
         V3 cur_o = mk(qa.x, qa.y, qa.z), cur_d = mk(qb.x, qb.y, qb.z);      // the path's current ray (pending calls only)
         float *trk = pl.trk + (size_t)slot * pl.ntrk;
-        // The direct lighting of the frame that cast the shadow rays whose terms arrived with this entry -- the caller
-        // of a pending call, or the parked frame itself: the contributions of the rays connect found free, added in
-        // the order of HandleDiffuseMaterial (sky sample :538-540, lights :557-559, emissive sample :617).
-        V3 pdirect = mk(0, 0, 0);
-        if (pneed >> pl.nshadow) { err |= ERR_PHASE; pneed = 0; }
-        for (int k = 0; k < pl.nshadow; ++k) {
-            if (!(pneed >> k & 1u)) continue;
-            const float4 v = pterms[k];
-            uint32_t qi = f2u(v.w);
-            if (qi >= pl.cap * (uint32_t)pl.nshadow) { err |= ERR_SLOT; qi = 0; }
-            if (pl.q_sray_occ[qi] == 0u) pdirect = add(pdirect, mk(v.x, v.y, v.z));
-        }
         // arguments of a child call pushed in this invocation (they go into its queue entry when the path parks)
         int arg_bounces = 0, arg_bindex = 0; uint32_t arg_flags = 0; float arg_energy = 0.0f; V3 arg_ln = mk(0, 0, 0);
         float4 *frames = pl.fr + (size_t)slot * pl.nframes * 8;
@@ -591,27 +1298,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         auto trk_previous = [&]() -> float { return trk_len < 2 ? 1.0f : trk_get(trk_len - 2); };
 
         // (re)derive the hit of the top frame from what the frame stores
-        auto load_hit = [&](Hit &h) {
-            h.ro = FV(F_RO); h.rd = FV(F_RD);
-            h.prim = FI(F_PRIM);
-            if ((uint32_t)h.prim >= sc.ntris) { err |= ERR_PRIM; h.prim = 0; }
-            float t = FW(F_T);
-            h.P = add(h.ro, scale(h.rd, t));                                        // tracer.go:37
-            STri tr = load_stri(sc, (uint32_t)h.prim);
-            if (tr.mat >= sc.nmats) { err |= ERR_MAT; tr.mat = 0; }
-            h.A = tr.A; h.B = tr.B; h.C = tr.C;
-            V3 n = normalize(interpolate_normal(h.P, h.A, h.B, h.C, tr.N0, tr.N1, tr.N2));   // :38-46
-            if (f_flags() & FL_FLIPPED) n = scale(n, -1.0f);                        // :53
-            h.normal = n;
-            h.mat = tr.mat;
-            h.dnormal = n;
-            diffuse_surface(sc.mats[h.mat], sc.uvs, sc.tex, sc.ntex, sc.tex_pixels, (uint32_t)h.prim, h.P, h.A, h.B, h.C,
-                            h.albedo, h.dnormal);
-        };
-        // park the top frame and make a child TraceRay invocation the pending call; the caller requests its extend
+        auto load_hit = [&](Hit &h) { derive_hit(sc, FV(F_RO), FV(F_RD), FW(F_T), FI(F_PRIM), (f_flags() & FL_FLIPPED) != 0, h, err); };
+        // park the top frame and make a child TraceRay invocation the pending call; the caller requests its extend.
+        // A child inherits FL_ANC, and gets it when the frame it leaves behind waits for its refraction subtree.
         auto push_child = [&](int dep, int bounces, int bindex, V3 lastN, bool specular, float energy, V3 o, V3 d) {
             store_frame(dep);
-            arg_bounces = bounces; arg_bindex = bindex; arg_flags = specular ? (uint32_t)FL_SPECULAR : 0u;
+            arg_bounces = bounces; arg_bindex = bindex;
+            arg_flags = (specular ? (uint32_t)FL_SPECULAR : 0u) | ((f_flags() & FL_ANC) || f_phase() == (uint32_t)PH_REFR_WAIT ? (uint32_t)FL_ANC : 0u);
             arg_energy = energy; arg_ln = lastN;
             cur_o = o; cur_d = d;
         };
@@ -622,10 +1315,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         bool have_hit = false;
         // entry: a pending call starts from its arguments, a parked frame comes back with its shadow answers
         if (pending) {
-            const int ab = f2i(a1.x), abi = f2i(a1.y);
-            FU_SET(F_BB, ((uint32_t)ab & 0xFFFFu) | ((uint32_t)abi & 0xFFu) << 16 | (f2u(a1.z) & 0xFFu) << 24);
-            FW(F_ENERGY) = a1.w;
-            FW(F_LN) = a2.x; FW(F_LN + 1) = a2.y; FW(F_LN + 2) = a2.z;
+            FU_SET(F_BB, ((uint32_t)in_bounces & 0xFFFFu) | ((uint32_t)in_bindex & 0xFFu) << 16 | (in_flags & ~(uint32_t)FL_FLIPPED) << 24);
+            FW(F_ENERGY) = in_energy;
+            FW(F_LN) = in_ln.x; FW(F_LN + 1) = in_ln.y; FW(F_LN + 2) = in_ln.z;
             FV_SET(F_PDIRECT, pdirect);                                     // handed back to the caller when this call returns
             FU_SET(F_SP, (uint32_t)PH_EXTEND << 24);
             state = ST_EXTENDED;
@@ -724,76 +1416,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     FV_SET(F_DIFF, dc);
                     state = ST_COMBINE; continue;
                 }
-                // direct lighting of HandleDiffuseMaterial (:523-618): draw in the reference's order and stage the shadow
-                // rays.  A ray's contribution is staged as the term the final sum adds if the ray is free (lights:
-                // albedo * Sample(...), :557-559); the terms travel with the path's next queue entry and are summed at its
-                // next visit, once `connect` has answered the rays.
-                const V3 albedo = h.albedo;
-                const V3 rayOrigin = add(h.P, scale(h.dnormal, (float)0.001));                       // :528
-                uint32_t need = 0;
-                auto stage = [&](int k, V3 d, float range, V3 term) {
-                    need |= 1u << k;
+                // direct lighting of HandleDiffuseMaterial (:523-618): the shadow rays are staged in LDS
+                const uint32_t need = direct_lighting(sc, ra, h, rng, sh_o, sh_eo, err, [&](int k, V3 d, float range, V3 term) {
                     float *sr = s_ray + (size_t)stage_word(k) * 256 + tid;
                     sr[0] = d.x; sr[256] = d.y; sr[512] = d.z;
                     sr[768] = term.x; sr[1024] = term.y; sr[1280] = term.z;
                     if (k) sr[1536] = range;
                     n_sray++;
-                };
-                sh_o = rayOrigin;
-                if (sc.sky.kind != PTMI_SKY_NONE) {                                                 // :531-542
-                    V3 t1, t2; tangent_frame(h.dnormal, t1, t2);
-                    V3 rn = cosine_sample2(rng, h.dnormal, t1, t2);
-                    stage(0, rn, SKY_RAY_RANGE, cmul(sky_sample(sc.sky, sc.sky_img, rn), albedo));
-                }
-                for (uint32_t li = 0; li < sc.nlights; ++li) {                                      // :545-560
-                    const PtLight &L = sc.lights[li];
-                    if (L.kind == PTMI_LIGHT_SUN) {                                                 // lights.go:18-28
-                        V3 ld = mk(L.vec);
-                        float ndotr = dot(ld, h.dnormal);
-                        if (!(ndotr < 0.0f)) stage(1 + li, ld, ra.p.step_size, cmul(albedo, scale(mk(L.color), ndotr * L.intensity)));
-                    } else {                                                                        // lights.go:38-54
-                        V3 ld = normalize(sub(mk(L.vec), rayOrigin));
-                        V3 toLight = sub(mk(L.vec), rayOrigin);
-                        float distance = length(toLight);
-                        toLight = normalize(toLight);
-                        float ndotl = dot(h.dnormal, toLight);
-                        if (!(ndotl <= 0.0f)) {
-                            float att = 1.0f / (distance * distance);
-                            stage(1 + li, ld, distance, cmul(albedo, scale(mk(L.color), ndotl * L.intensity * att)));
-                        }
-                    }
-                }
-                if (sc.nemissive > 0) {                                                             // :562-618
-                    V3 eo = add(h.P, scale(h.dnormal, (float)0.01));
-                    sh_eo = eo;
-                    uint32_t choice = rng_intn(rng, sc.nemissive);
-                    uint32_t et = sc.emissive[choice];
-                    if (et >= sc.ntris) { err |= ERR_PRIM; et = 0; }
-                    STri e = load_stri(sc, et);
-                    if (e.mat >= sc.nmats) { err |= ERR_MAT; e.mat = 0; }
-                    V3 lightPoint = sample_triangle_point(rng, e.A, e.B, e.C);
-                    V3 lsn = interpolate_normal(lightPoint, e.A, e.B, e.C, e.N0, e.N1, e.N2);
-                    V3 toLight = sub(lightPoint, eo);
-                    float distance = length(toLight);
-                    toLight = normalize(toLight);
-                    float ndotl = dot(toLight, h.dnormal);
-                    if (!(ndotl <= 0.0f)) {
-                        V3 ec = mk(0, 0, 0);
-                        float sndorl = -dot(toLight, lsn);
-                        if (!(sndorl <= 0.0f)) {
-                            float geometryTerm = ndotl * sndorl / (distance * distance);
-                            float pdf = triangle_area(e.A, e.B, e.C);
-                            pdf = 1.0f / (pdf * (float)sc.nemissive);
-                            float pdf_brdf = dot(h.dnormal, toLight) / PT_PI32;
-                            float pdf_sa = pdf * (distance * distance) / sndorl;
-                            float weight = mis_weight(pdf_sa, pdf_brdf);
-                            V3 le = mk(sc.mats[e.mat].ke);
-                            V3 brdf = scale(albedo, (float)(1.0 / 3.14159265358979323846));
-                            ec = scale(cmul(le, brdf), geometryTerm * weight / pdf);
-                        }
-                        stage(1 + (int)sc.nlights, toLight, distance - (float)0.01, ec);
-                    }
-                }
+                });
                 need_out = need;
                 FV_SET(F_DIFF, mk(0, 0, 0));         // this frame's direct lighting until the terms have been summed
                 // A frame with a GI child to wait for anyway does not park for its shadow rays: they are traced while
@@ -823,13 +1453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (state == ST_DIFFUSE_FINAL) {                                                        // :658-667
                 uint32_t fmat = FU(F_MAT);
                 if (fmat >= sc.nmats) { err |= ERR_MAT; fmat = 0; }
-                const PtMaterial &m = sc.mats[fmat];
-                V3 indirect = f_bounces() > 0 ? FV(F_SUM) : mk(0, 0, 0);
-                const V3 albedo = FV(F_ALBEDO);
-                V3 fin = FV(F_DIFF);                 // direct lighting: the free shadow rays' terms (summed at entry / by the child)
-                fin = add(fin, scale(albedo, ra.p.ambient));
-                fin = add(fin, scale(indirect, 1.0f));
-                if (f_bindex() == 0 && is_emissive(m)) fin = add(fin, mk(m.ke));
+                const V3 fin = diffuse_final(sc, ra, fmat, f_bounces(), f_bindex(), FV(F_DIFF), FV(F_SUM), FV(F_ALBEDO));
                 diffuse_events++;
                 FV_SET(F_DIFF, fin);
                 FV_SET(F_SUM, mk(0, 0, 0));          // reflective component stays zero on this branch
@@ -858,17 +1482,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     depth++; want_extend = true; pushed = true; break;
                 }
                 if (pushed) break;
-                V3 sum = scale(FV(F_SUM), 1.0f / (float)ra.p.scatter_rays);
-                sum = cmul(sum, mk(m.ks));
-                FV_SET(F_SUM, add(sum, FV(F_REFR)));                                                // :165, :211
+                FV_SET(F_SUM, reflective_final(sc, ra, fmat, FV(F_SUM), FV(F_REFR)));               // :716-721, :165, :211
                 state = ST_COMBINE; continue;
             }
             if (state == ST_COMBINE) {                                                              // :218-223
-                V3 refr = FV(F_REFR);
-                float diffuseScale = 1.0f;
-                if (length(refr) > 0.0f) diffuseScale = (float)0.1;
-                V3 fin = add(add(add(scale(FV(F_DIFF), diffuseScale), mk(0, 0, 0)), FV(F_SUM)), refr);
-                ret = scale(fin, FW(F_DG));
+                ret = combine_components(FV(F_DIFF), FV(F_SUM), FV(F_REFR), FW(F_DG));
                 state = ST_RETURN; continue;
             }
             // ST_RETURN: hand `ret` to the caller frame, and with it the caller's direct lighting this call carried
@@ -902,11 +1520,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             want_extend = want_shadow = false; n_sray = 0; need_out = 0; finished = true; store_to = nullptr;
         }
         if (!finished) {      // the state that travels with the path, for its next queue entry
-            out_a0 = make_float4(a0.x, a0.y, u2f(rng.ctr), u2f((uint32_t)depth | trk_len << 8));
-            out_a2 = make_float4(arg_ln.x, arg_ln.y, arg_ln.z, trk0);
+            out_sid = sid; out_key = rng.key; out_ctr = rng.ctr; out_trk0 = trk0;
+            out_depth_trk = (uint32_t)depth | trk_len << 8;
+            // a parked frame is unwound by the lean kernel unless a refraction frame waits below it
+            if (want_shadow) anc_out = (f_flags() & FL_ANC) != 0 || ra.p.scatter_rays != 1;
             // the child pushed right after staging carries the staged rays' terms (need_out), any other child none
             if (want_extend) {
-                out_a1 = make_float4(i2f(arg_bounces), i2f(arg_bindex), u2f(arg_flags | need_out << 8), arg_energy);
+                out_pack = pack_call(depth, trk_len, arg_bounces, arg_bindex);
+                out_flags = arg_flags | need_out << 8;
+                out_ctx = call_ctx(arg_bounces, arg_bindex, arg_energy, arg_flags);
+                out_energy = arg_energy; out_ln = arg_ln;
                 out_o = cur_o; out_d = cur_d;
             }
         }
@@ -918,122 +1541,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #undef FI_SET
 #undef FU_SET
     }
-    // ---- parked frames: the wave stores them together, lane 8 g + j writing quarter-line j of the frames of lanes
-    // 8 g .. 8 g + 7 in turn (the frames are still in this wave's LDS columns; the compaction below reuses them) ----
+    // ---- parked frames: the wave stores them together, 8 lanes per line (the frames are still in this wave's LDS
+    // columns; the compaction below reuses them) ----
+    wave_store_lines(s_fw + threadIdx.x, 256, store_to, FRW);
+    // ---- queue compaction: one atomic per workgroup and queue (tail_reserve; its bookkeeping words have a small LDS
+    // area of their own: other waves may still be in their state machines, so the frame area cannot lend them) ----
+    __shared__ float s_q[BK_N * 4];
+    TailOut to;
+    to.want_extend = want_extend; to.want_shadow = want_shadow; to.finished = finished; to.anc = anc_out; to.need_out = need_out; to.slot = slot;
+    const TailPos tp = tail_reserve(pl, cur, s_q, to, diffuse_events, counters);
     {
-        const unsigned long long m_st = __ballot(store_to != nullptr);
-        if (m_st) {
-            const int lane = threadIdx.x & 63, grp = lane & ~7, sub = lane & 7;
-            const uint32_t lo = (uint32_t)(uintptr_t)store_to, hi = (uint32_t)((uintptr_t)store_to >> 32);
-            for (int i = 0; i < 8; ++i) {
-                const int src = grp + i;
-                const uint32_t slo = (uint32_t)__shfl((int)lo, src), shi = (uint32_t)__shfl((int)hi, src);
-                if (m_st >> src & 1ull) {
-                    float4 *dst = (float4 *)(((uintptr_t)shi << 32) | (uintptr_t)slo);
-                    const float *col = s_fw + (threadIdx.x & ~63u) + (uint32_t)src;
-                    dst[sub] = make_float4(col[(4 * sub) * 256], col[(4 * sub + 1) * 256], col[(4 * sub + 2) * 256],
-                                           4 * sub + 3 < FRW ? col[(4 * sub + 3) * 256] : 0.0f);
-                }
-            }
-        }
-    }
-    // ---- queue compaction: one atomic per workgroup and queue (ballot + popcount per wave, 4 waves summed in LDS) ----
-    {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const unsigned long long m_ext = __ballot(want_extend), m_shp = __ballot(want_shadow), m_fin = __ballot(finished);
-        // shadow rays by bucket: kinds 0 .. NSB-2 are one ray per lane at most (ballot), the last bucket can take several
-        const uint32_t last_bits = need_out >> (NSB - 1);
-        uint32_t incl = (uint32_t)__popc(last_bits);
-        if (pl.nshadow >= NSB) {
-            for (int off = 1; off < 64; off <<= 1) {
-                uint32_t v = __shfl_up(incl, off);
-                if (lane >= off) incl += v;
-            }
-        }
-        unsigned long long m_ray[NSB - 1];
-#pragma unroll
-        for (int b = 0; b < NSB - 1; ++b) m_ray[b] = __ballot((need_out >> b) & 1u);
-        for (int off = 32; off > 0; off >>= 1) diffuse_events += __shfl_xor(diffuse_events, off);
-        // [queue][wave] counts, then bases (ext, shadow paths, free, NSB ray buckets), in the frame area: wave w uses
-        // words of its OWN threads' columns (frame word 0 of threads 64 w + q), which are dead now that the whole wave
-        // has left the state machine; other waves may still be in theirs
-        // (kept as float bit patterns: one access type per LDS word, no type-punned pointer for the optimiser to reorder around)
-#define SQ(q, w) f2u(s_fw[(w) * 64 + (q)])
-#define SQ_SET(q, w, v) (s_fw[(w) * 64 + (q)] = u2f(v))
-        if (lane == 63) {
-            SQ_SET(0, wv, (uint32_t)__popcll(m_ext)); SQ_SET(1, wv, (uint32_t)__popcll(m_shp));
-            SQ_SET(2, wv, (uint32_t)__popcll(m_fin));
-#pragma unroll
-            for (int b = 0; b < NSB - 1; ++b) SQ_SET(3 + b, wv, (uint32_t)__popcll(m_ray[b]));
-            SQ_SET(3 + NSB - 1, wv, pl.nshadow >= NSB ? incl : 0u);
-        }
-        lds_barrier();
-        if (threadIdx.x < 3 + NSB) {
-            const int q = threadIdx.x;
-            const uint32_t c0 = SQ(q, 0), c1 = SQ(q, 1), c2 = SQ(q, 2), c3 = SQ(q, 3);
-            const uint32_t total = c0 + c1 + c2 + c3;
-            unsigned long long *ctr = q == 0 ? qc_ext_next : q == 1 ? qc_shp_next : &pl.qcnt[(size_t)(QC_FREE + (q - 2)) * QC_STRIDE];
-            uint32_t base = 0;
-            if (total) base = (uint32_t)atomicAdd(ctr, (unsigned long long)total);
-            SQ_SET(q, 0, base); SQ_SET(q, 1, base + c0); SQ_SET(q, 2, base + c0 + c1); SQ_SET(q, 3, base + c0 + c1 + c2);
-            if (q == 2 && total) atomicAdd(&counter_shard(counters)[CNT_SAMPLES], (unsigned long long)total);
-        }
-        if (lane == 0 && diffuse_events) atomicAdd(&counter_shard(counters)[CNT_DIFFUSE], (unsigned long long)diffuse_events);
-        lds_barrier();
-        // where this path's shadow terms go: beside its extend entry or its shadow-wait entry
-        float4 *terms_out = nullptr;
-        {
-            // The wave's extend entries are contiguous in both arrays (positions base .. base + count - 1), so they are
-            // put together in LDS -- rows 1.. of the frame area, this wave's own columns, dead like row 0 -- and written
-            // out as whole lines: per-lane stores 32 / 48 bytes apart cost generate a third of its time.
-            const uint32_t base_e = SQ(0, wv), cnt_e = (uint32_t)__popcll(m_ext), j = (uint32_t)__popcll(m_ext & lt);
-            float4 *stg = (float4 *)(s_fw + 256 + 64 * wv);                 // float4 number k of the wave's flat staging area:
-            auto at = [&](uint32_t k) -> float4 & { return stg[(k >> 4) * 64 + (k & 15)]; };   // 16 per row segment
-            enum { STG_ARG = 2 * 64 };                                      // rays first (2 per entry), then arguments (QA per entry)
-            static_assert((STG_ARG + QA * 64 + 15) / 16 + 1 <= FRW, "the staging area fits the frame rows");
-            if (want_extend) {
-                at(2 * j) = make_float4(out_o.x, out_o.y, out_o.z, u2f(slot));
-                at(2 * j + 1) = make_float4(out_d.x, out_d.y, out_d.z, 1.0f);
-                at(STG_ARG + QA * j) = out_a0; at(STG_ARG + QA * j + 1) = out_a1; at(STG_ARG + QA * j + 2) = out_a2;
-                terms_out = q_ext_sh_next + ((size_t)base_e + j) * (size_t)pl.nshadow;
-            }
-            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own LDS writes, before its lanes read them
-            float4 *dr = q_ray_next + 2 * (size_t)base_e, *da = q_arg_next + QA * (size_t)base_e;
-            for (uint32_t k = lane; k < 2 * cnt_e; k += 64) dr[k] = at(k);
-            for (uint32_t k = lane; k < QA * cnt_e; k += 64) da[k] = at(STG_ARG + k);
+        // The child's record is put together in the frame area (this thread's column: the frame store above has read
+        // it, and LDS accesses of one wave complete in order) and stored as a whole line, like the frames.
+        float *w = s_fw + threadIdx.x;
+        float4 *rec_dst = nullptr, *shp_terms = nullptr;
+        if (want_extend) {
+            rec_dst = rec_at(pl, cur ^ 1, tp.ext);
+            w[R_O * 256] = out_o.x; w[(R_O + 1) * 256] = out_o.y; w[(R_O + 2) * 256] = out_o.z;
+            w[R_SLOT * 256] = u2f(slot | out_ctx << CTX_SHIFT);
+            w[R_D * 256] = out_d.x; w[(R_D + 1) * 256] = out_d.y; w[(R_D + 2) * 256] = out_d.z;
+            w[R_SID * 256] = u2f(out_sid);
+            w[R_HIT * 256] = 0.0f; w[R_T * 256] = 0.0f;
+            w[R_KEY * 256] = u2f(out_key); w[R_CTR * 256] = u2f(out_ctr);
+            w[R_PACK * 256] = u2f(out_pack); w[R_FLAGS * 256] = u2f(out_flags);
+            w[R_ENERGY * 256] = out_energy; w[R_TRK0 * 256] = out_trk0;
+            w[R_LN * 256] = out_ln.x; w[(R_LN + 1) * 256] = out_ln.y; w[(R_LN + 2) * 256] = out_ln.z;
+            for (int k = R_TERMS; k < FRW; ++k) w[k * 256] = 0.0f;
         }
         if (want_shadow) {
-            const size_t ps = SQ(1, wv) + (uint32_t)__popcll(m_shp & lt);
-            q_shpath_next[2 * ps] = make_float4(u2f(slot), out_a0.x, out_a0.y, out_a0.z);
-            q_shpath_next[2 * ps + 1] = make_float4(out_a0.w, out_a2.w, u2f(need_out), 0.0f);
-            terms_out = q_shp_sh_next + ps * (size_t)pl.nshadow;
+            const size_t ps = shp_entry(pl, tp.shp, tp.shp_back);
+            pl.q_shpath[cur ^ 1][2 * ps] = make_float4(u2f(slot), u2f(out_sid), u2f(out_key), u2f(out_ctr));
+            pl.q_shpath[cur ^ 1][2 * ps + 1] = make_float4(u2f(out_depth_trk), out_trk0, u2f(need_out), u2f(anc_out ? (uint32_t)FL_ANC : 0u));
+            shp_terms = pl.q_shp_sh[cur ^ 1] + ps * (size_t)pl.nshadow;
         }
-        if (finished) pl.q_free[SQ(2, wv) + (uint32_t)__popcll(m_fin & lt)] = slot;
-        if (n_sray && terms_out) {
-            uint32_t pos_last = SQ(3 + NSB - 1, wv) + (incl - (uint32_t)__popc(last_bits));
-            for (int k = 0; k < pl.nshadow; ++k) {
-                if (!(need_out >> k & 1u)) continue;
-                uint32_t pos;
-                if (k < NSB - 1) {
-                    unsigned long long m = 0;
-#pragma unroll
-                    for (int b = 0; b < NSB - 1; ++b) if (b == k) m = m_ray[b];
-                    pos = SQ(3 + k, wv) + (uint32_t)__popcll(m & lt);
-                } else {
-                    pos = pos_last++;
-                }
-                const int b = k < NSB - 1 ? k : NSB - 1;
-                const size_t qi = (size_t)b * pl.cap + pos;
-                const V3 o = k == pl.nshadow - 1 ? sh_eo : sh_o;            // the emissive sample starts from its own offset (:563)
-                const float *sr = s_ray + (size_t)stage_word(k) * 256 + threadIdx.x;
-                pl.q_sray_a[qi] = make_float4(o.x, o.y, o.z, k ? sr[1536] : SKY_RAY_RANGE);
-                pl.q_sray_b[qi] = make_float4(sr[0], sr[256], sr[512], 0.0f);
-                terms_out[k] = make_float4(sr[768], sr[1024], sr[1280], u2f((uint32_t)qi));
-            }
+        if (finished) pl.q_free[tp.fin] = slot;
+        if (n_sray && (rec_dst || shp_terms)) {
+            const int ninl = pl.rec_inline;
+            flush_shadow_rays(pl, s_ray, need_out, tp, sh_o, sh_eo, [&](int k, float4 term) {
+                if (shp_terms) { shp_terms[k] = term; return; }
+                if (k >= ninl) { rec_dst[REC_BASE / 4 + (k - ninl)] = term; return; }
+                float *t = w + (size_t)(R_TERMS + 4 * k) * 256;
+                t[0] = term.x; t[256] = term.y; t[512] = term.z; t[768] = term.w;
+            });
         }
-#undef SQ
-#undef SQ_SET
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own LDS writes, before its lanes read them
+        wave_store_lines(w, 256, rec_dst, FRW);
     }
 }
 
@@ -1093,6 +1645,7 @@ struct RenderState {
     // scene (device)
     bool have_scene = false;
     float4 *d_stri = nullptr;            // per-triangle shading record (DevScene::stri)
+    uint8_t *d_tri_class = nullptr;      // TC_* bits per triangle (DevScene::tri_class)
     uint32_t nmats = 0;
     float *d_uvs = nullptr; TexDesc *d_tex = nullptr; uint32_t *d_tex_pixels = nullptr; uint32_t ntex = 0;
     PtMaterial *d_mats = nullptr; uint32_t *d_emissive = nullptr; uint32_t nemissive = 0;
@@ -1101,7 +1654,7 @@ struct RenderState {
     PtBlackHole bh{}; int has_bh = 0;
     // pool (device), sized for (cap, bounces, nlights)
     char *pool_mem = nullptr; size_t pool_bytes = 0;
-    uint32_t pool_cap = 0; int pool_bounces = -2, pool_nlights = -1, pool_lanes = 0;
+    uint32_t pool_cap = 0; int pool_bounces = -2, pool_nlights = -1, pool_lanes = 0, pool_curved = -1;
     enum { MAX_LANES = 4, QC_RING = 2 };
     Pool pools[MAX_LANES]{};             // one per lane (render_core)
     hipStream_t lane_stream[MAX_LANES] = {};   // lanes 1 .. run here, lane 0 on the caller's stream
@@ -1127,7 +1680,7 @@ void invalidate_scene(ptmi_ctx *ctx) {
 void free_scene(ptmi_ctx *ctx) {
     RenderState *rs = ctx->render;
     if (!rs) return;
-    void *ptrs[] = {rs->d_uvs, rs->d_tex, rs->d_tex_pixels, rs->d_stri, rs->d_mats, rs->d_emissive, rs->d_lights,
+    void *ptrs[] = {rs->d_uvs, rs->d_tex, rs->d_tex_pixels, rs->d_stri, rs->d_tri_class, rs->d_mats, rs->d_emissive, rs->d_lights,
                     rs->d_sky_img, rs->pool_mem, rs->d_out, rs->d_accum, rs->d_counts, rs->d_tiles};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &lane : rs->ev_qc) for (hipEvent_t e : lane) if (e) (void)hipEventDestroy(e);
@@ -1159,6 +1712,7 @@ extern "C" int ptmi_upload_scene(ptmi_ctx *ctx, const PtMaterial *materials, uin
         return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: null array");
     // shade stages a path's shadow rays (one per light + 2) in LDS: 7 KB per ray kind beside the 32 KB of frames
     if (nlights > 16) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: at most 16 lights");
+    if (ntris >= (1ull << 30)) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: at most 2^30 - 1 triangles (a queue record keeps the primitive in 30 bits)");
     for (uint64_t t = 0; t < ntris; ++t)
         if (tri_material[t] >= nmaterials) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: material index out of range");
     if (sky->kind < 0 || sky->kind > 3) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_upload_scene: bad sky kind");
@@ -1186,6 +1740,24 @@ extern "C" int ptmi_upload_scene(ptmi_ctx *ctx, const PtMaterial *materials, uin
         if ((rc = upload(ctx, d, rec.data(), rec.size()))) return rc;
         if (rs->d_stri) (void)hipFree(rs->d_stri);
         rs->d_stri = (float4 *)d;
+    }
+    {   // what extend needs to know about a hit triangle to name the entry's class (classify): the branch TraceRay takes
+        // on its material -- glass by name (tracer.go:49), the accretion disk (:95, only with a black hole in the
+        // scene), reflectivity = mean(Ks) against 0.1 / 0.9 (:116-163, the same float32 expression as the kernels'),
+        // emitter (:461)
+        std::vector<uint8_t> mc((size_t)nmaterials), tc((size_t)ntris + 1, 0);
+        for (uint64_t k = 0; k < nmaterials; ++k) {
+            const PtMaterial &m = materials[k];
+            const float reflectivity = (m.ks[0] + m.ks[1] + m.ks[2]) / 3.0f;
+            uint8_t c = 0;
+            if (m.flags & PTMI_MAT_GLASS) c |= TC_GLASS;
+            if ((m.flags & PTMI_MAT_ACCRETION) && blackhole) c |= TC_ACCR;
+            if (!(reflectivity < (float)0.1)) c |= (reflectivity < (float)0.9) ? TC_MID : TC_REFL;
+            if (m.ke[0] > 0.0f || m.ke[1] > 0.0f || m.ke[2] > 0.0f) c |= TC_EMIT;
+            mc[k] = c;
+        }
+        for (uint64_t t = 0; t < ntris; ++t) tc[t] = mc[tri_material[t]];
+        if ((rc = upload(ctx, rs->d_tri_class, tc.data(), tc.size()))) return rc;
     }
     if ((rc = upload(ctx, rs->d_mats, materials, (size_t)nmaterials))) return rc;
     if ((rc = upload(ctx, rs->d_lights, lights, (size_t)nlights))) return rc;
@@ -1250,34 +1822,44 @@ static int tracker_words(int bounces) {
     int ntrk = bounces + 1 >= 6 ? 64 : (1 << (bounces + 1)) + 1;
     return (ntrk + 3) / 4 * 4;
 }
+// float4s of an extend-queue record: words 0 .. 31 hold the call and the first rec_inline shadow terms (a curved
+// ray's record keeps extend's V_t pair in words 28-29 instead of a third term), the other terms follow from word 32;
+// whole 64-byte sectors
+static int record_inline_terms(bool curved) { return curved ? 2 : 3; }
+static int record_quads(int nshadow, bool curved) {
+    const int extra = std::max(0, nshadow - record_inline_terms(curved));
+    return (REC_BASE + 4 * extra + 15) / 16 * 4;
+}
 // device bytes one path of the pool takes (records + its share of every queue)
-static uint64_t pool_bytes_per_path(int bounces, int nlights) {
+static uint64_t pool_bytes_per_path(int bounces, int nlights, bool curved) {
     const uint64_t nframes = (uint64_t)bounces + 1, nshadow = (uint64_t)nlights + 2;
-    // frames + tracker history + shadow-ray queue (ray, answer) and the shadow terms beside both path queues (double
-    // buffered) + extend queue (ray, state: double buffered; answer) + shadow-wait queue (double buffered) + free list
-    return 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (32 + 4 + 16 * 4) * nshadow + (32 + 16 * QA) * 2 + 16 + 32 * 2 + 4;
+    // frames + tracker history + shadow-ray queue (ray, answer) and the shadow terms beside the shadow-wait queue (double
+    // buffered) + extend queue (records, double buffered; class byte; index lists) + shadow-wait queue (double
+    // buffered) + free list
+    return 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (32 + 4 + 16 * 2) * nshadow + 16 * (uint64_t)record_quads((int)nshadow, curved) * 2 +
+           1 + 4 * NLIST + 32 * 2 + 4;
 }
 
-static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
+static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes, bool curved) {
     RenderState *rs = ctx->render;
     if (rs->pool_mem && rs->pool_cap >= cap && rs->pool_bounces == bounces && rs->pool_nlights == (int)rs->nlights &&
-        rs->pool_lanes >= lanes)
+        rs->pool_lanes >= lanes && rs->pool_curved == (int)curved)
         return PTMI_OK;                  // a larger pool of the same shape serves (tiles of different sizes)
     if (rs->pool_mem) { (void)hipFree(rs->pool_mem); rs->pool_mem = nullptr; }
     const int nframes = bounces + 1, nshadow = (int)rs->nlights + 2;
     const int ntrk = tracker_words(bounces);
+    const int rec_q = record_quads(nshadow, curved);
     const size_t c = cap;
-    struct Off { size_t fr, trk, qs0, qs1, ra, rb, occ, qr0, qr1, qa0, qa1, qh, xs0, xs1, ss0, ss1, free_, cnt, it; } of[RenderState::MAX_LANES];
+    struct Off { size_t fr, trk, qs0, qs1, ra, rb, occ, rec0, rec1, cls, idx, ss0, ss1, free_, cnt, it; } of[RenderState::MAX_LANES];
     size_t off = 0;
     for (int l = 0; l < lanes; ++l) {
         Off &o = of[l];
         o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
         o.qs0 = carve(off, 32 * c); o.qs1 = carve(off, 32 * c);
         o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow); o.occ = carve(off, 4 * c * nshadow);
-        o.xs0 = carve(off, 16 * c * nshadow); o.xs1 = carve(off, 16 * c * nshadow);
         o.ss0 = carve(off, 16 * c * nshadow); o.ss1 = carve(off, 16 * c * nshadow);
-        o.qr0 = carve(off, 32 * c); o.qr1 = carve(off, 32 * c);
-        o.qa0 = carve(off, 16 * QA * c); o.qa1 = carve(off, 16 * QA * c); o.qh = carve(off, 16 * c);
+        o.rec0 = carve(off, 16 * c * rec_q); o.rec1 = carve(off, 16 * c * rec_q);
+        o.cls = carve(off, c + BIN_CHUNK); o.idx = carve(off, 4 * c * NLIST);
         o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * QC_COUNT * QC_STRIDE); o.it = carve(off, sizeof(IterArgs));
     }
     if (hipMalloc((void **)&rs->pool_mem, off) != hipSuccess) {
@@ -1291,20 +1873,19 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes) {
         const Off &o = of[l];
         Pool p{};
         p.cap = cap; p.nframes = nframes; p.nshadow = nshadow; p.ntrk = ntrk;
+        p.rec_q = rec_q; p.rec_inline = record_inline_terms(curved);
         p.fr = (float4 *)(b + o.fr); p.trk = (float *)(b + o.trk);
-        p.q_ext_sh[0] = (float4 *)(b + o.xs0); p.q_ext_sh[1] = (float4 *)(b + o.xs1);
         p.q_shp_sh[0] = (float4 *)(b + o.ss0); p.q_shp_sh[1] = (float4 *)(b + o.ss1);
         p.q_sray_occ = (uint32_t *)(b + o.occ);
-        p.q_ext_ray[0] = (float4 *)(b + o.qr0); p.q_ext_ray[1] = (float4 *)(b + o.qr1);
-        p.q_ext_arg[0] = (float4 *)(b + o.qa0); p.q_ext_arg[1] = (float4 *)(b + o.qa1);
-        p.q_ext_hit = (float4 *)(b + o.qh);
+        p.q_rec[0] = (float4 *)(b + o.rec0); p.q_rec[1] = (float4 *)(b + o.rec1);
+        p.q_cls = (uint8_t *)(b + o.cls); p.q_idx = (uint32_t *)(b + o.idx);
         p.q_shpath[0] = (float4 *)(b + o.qs0); p.q_shpath[1] = (float4 *)(b + o.qs1);
         p.q_sray_a = (float4 *)(b + o.ra); p.q_sray_b = (float4 *)(b + o.rb);
         p.q_free = (uint32_t *)(b + o.free_); p.qcnt = (unsigned long long *)(b + o.cnt);
         p.it = (IterArgs *)(b + o.it);
         rs->pools[l] = p;
     }
-    rs->pool_cap = cap; rs->pool_bounces = bounces; rs->pool_nlights = (int)rs->nlights; rs->pool_lanes = lanes;
+    rs->pool_cap = cap; rs->pool_bounces = bounces; rs->pool_nlights = (int)rs->nlights; rs->pool_lanes = lanes; rs->pool_curved = (int)curved;
     return PTMI_OK;
 }
 
@@ -1356,8 +1937,8 @@ static void prof_collect(ptmi_ctx *ctx) {
 // One iteration of the wavefront loop on queue buffer `cur`, enqueued without knowing its sizes (IterArgs); the grids
 // cover the most paths the call can have in flight (the pool, or all of the call's samples if those are fewer).
 template <int STACK>
-static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, uint64_t lane_total, int cur,
-                               hipStream_t s) {
+static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, const BinMap &bm, uint64_t lane_total,
+                               int cur, hipStream_t s) {
     const uint64_t most = std::min<uint64_t>(pl.cap, lane_total);
     const unsigned cap_wgs = (unsigned)((most + 255) / 256), cap_waves = (unsigned)((most + WAVE - 1) / WAVE);
     if (ctx->profiling) ctx->prof_iterations++;
@@ -1372,7 +1953,7 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
         const unsigned pgrid = (unsigned)std::min<uint64_t>(cap_waves, (uint64_t)ctx->num_cus * per_cu);
         if (most >= vote_from)          // a call this small never has a queue that long: one launch less per iteration
             timed(ctx, PROF_EXTEND, s, [&] {
-                hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, cur, vote_from,
+                hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, sc.tri_class, ra, cur, vote_from,
                                    ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk); });
     }
     if (vote_from > 0) {
@@ -1402,22 +1983,28 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
         timed(ctx, PROF_CONNECT, s, [&] {
             hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, vote_from, ctx->d_counters); });
     }
-    // shade
+    // shade: the class bytes extend wrote become index lists, then one kernel per class (all three count as shade time)
     const size_t ray_lds = (size_t)(SRW * pl.nshadow - 1) * 256 * sizeof(float);
-    timed(ctx, PROF_SHADE, s, [&] { hipLaunchKernelGGL(shade_kernel, dim3(cap_wgs), dim3(256), ray_lds, s, pl, sc, ra, cur, ctx->d_counters); });
+    const size_t diff_lds = std::max(ray_lds, (size_t)XCH_WORDS * 256 * sizeof(float));
+    const unsigned bin_wgs = (unsigned)((most + BIN_CHUNK - 1) / BIN_CHUNK);
+    const unsigned ret_wgs = (unsigned)((most + 64 + 255) / 256), gen_wgs = (unsigned)((most + 64 * N_GEN + 255) / 256);
+    timed(ctx, PROF_SHADE, s, [&] { hipLaunchKernelGGL(bin_kernel, dim3(bin_wgs), dim3(256), 0, s, pl, bm); });
+    timed(ctx, PROF_SHADE, s, [&] { hipLaunchKernelGGL(shade_diff_kernel, dim3(cap_wgs), dim3(256), diff_lds, s, pl, sc, ra, cur, ctx->d_counters); });
+    timed(ctx, PROF_SHADE, s, [&] { hipLaunchKernelGGL(shade_ret_kernel, dim3(ret_wgs), dim3(256), 0, s, pl, sc, ra, cur, ctx->d_counters); });
+    timed(ctx, PROF_SHADE, s, [&] { hipLaunchKernelGGL(shade_kernel, dim3(gen_wgs), dim3(256), ray_lds, s, pl, sc, ra, cur, ctx->d_counters); });
     PTMI_HIP(ctx, hipGetLastError());
     return PTMI_OK;
 }
-static int enqueue_iteration(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, uint64_t lane_total, int cur,
-                             hipStream_t s) {
+static int enqueue_iteration(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, const BinMap &bm, uint64_t lane_total,
+                             int cur, hipStream_t s) {
     const int dep = ctx->stack_entries();
-    if (dep <= 16) return enqueue_iteration_t<16>(ctx, pl, sc, ra, lane_total, cur, s);
-    if (dep <= 20) return enqueue_iteration_t<20>(ctx, pl, sc, ra, lane_total, cur, s);
-    if (dep <= 24) return enqueue_iteration_t<24>(ctx, pl, sc, ra, lane_total, cur, s);
-    if (dep <= 28) return enqueue_iteration_t<28>(ctx, pl, sc, ra, lane_total, cur, s);
-    if (dep <= 32) return enqueue_iteration_t<32>(ctx, pl, sc, ra, lane_total, cur, s);
-    if (dep <= 48) return enqueue_iteration_t<48>(ctx, pl, sc, ra, lane_total, cur, s);
-    return enqueue_iteration_t<64>(ctx, pl, sc, ra, lane_total, cur, s);
+    if (dep <= 16) return enqueue_iteration_t<16>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    if (dep <= 20) return enqueue_iteration_t<20>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    if (dep <= 24) return enqueue_iteration_t<24>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    if (dep <= 28) return enqueue_iteration_t<28>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    if (dep <= 32) return enqueue_iteration_t<32>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    if (dep <= 48) return enqueue_iteration_t<48>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    return enqueue_iteration_t<64>(ctx, pl, sc, ra, bm, lane_total, cur, s);
 }
 
 // Renders samples [spp_begin, spp_begin+spp_count) of the rectangle into d_out chunks and accumulates them
@@ -1469,7 +2056,8 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     // Every wavefront iteration costs time that does not depend on the number of paths (the tails of three kernels
     // that wait for their longest rays), so the pool is as large as the work and the memory budget allow: 2 M paths
     // reach 640 Msamples/s on C3, 16 M reach 760 (profiles/r01c/README.md).
-    const uint64_t path_bytes = pool_bytes_per_path(bounces, (int)rs->nlights);
+    const bool curved = rs->has_bh != 0;
+    const uint64_t path_bytes = pool_bytes_per_path(bounces, (int)rs->nlights, curved);
     const uint64_t by_targets = 0xFFFFFFFFull / ((uint64_t)(bounces + 1) * (rs->nlights + 2));   // shadow-ray queue positions are 32-bit
     const uint64_t by_budget = std::min(by_targets, std::max<uint64_t>(1u << 16, ctx->pool_bytes_max / path_bytes));
     // Two independent loops ("lanes"), each on half of the pool and of the samples and on a stream of its own, when
@@ -1486,7 +2074,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     cap = (cap + 255) / 256 * 256;
     // the per-sample output buffer is in place (above); now as large a pool as fits
     int rc;
-    while ((rc = ensure_pool(ctx, cap, bounces, lanes)) == PTMI_ERR_OOM && cap > (1u << 16))
+    while ((rc = ensure_pool(ctx, cap, bounces, lanes, curved)) == PTMI_ERR_OOM && cap > (1u << 16))
         cap = (cap / 2 + 255) / 256 * 256;          // device memory is short (other contexts on this GPU): halve
     if (rc == PTMI_ERR_OOM) return set_err(ctx, PTMI_ERR_OOM, "ptmi_render: out of device memory for the path pool");
     if (rc) return rc;
@@ -1502,13 +2090,31 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     }
     {
         const size_t ray_lds = (size_t)(SRW * rs->pools[0].nshadow - 1) * 256 * sizeof(float);
-        if (ray_lds > (28u << 10))      // beyond the default 64 KB of LDS per workgroup (gfx950 has 160 KB)
+        if (ray_lds > (28u << 10)) {    // beyond the default 64 KB of LDS per workgroup (gfx950 has 160 KB)
             PTMI_HIP(ctx, hipFuncSetAttribute((const void *)shade_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds));
+            PTMI_HIP(ctx, hipFuncSetAttribute((const void *)shade_diff_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ray_lds));
+        }
     }
-
+    // Which list a class of queue entries goes to (bin_kernel).  The lean kernels take what they are written for: the
+    // returning calls when scatterRays == 1 (a frame that waits for its only ray finishes when it returns), plain
+    // diffuse hits -- those with no bounces left only when the scene has a sky, whose sample guarantees a shadow ray to
+    // wait for (with no ray at all the path goes straight on, which is the general kernel's business).
+    // PTMI_SHADE_SPLIT=0 sends everything to the general kernel (A/B, and the parity tests' bit-for-bit cross-check).
+    BinMap bm{};
+    {
+        const bool split = ctx->shade_split != 0;
+        const bool lean_ret = split && prm->scatter_rays == 1;
+        for (uint8_t &l : bm.list) l = L_G_OTHER;
+        bm.list[C_RET] = lean_ret ? L_RET : L_G_RET;
+        bm.list[C_RET_ANC] = L_G_RET;
+        bm.list[C_DIFF] = split ? L_DIFF : L_G_DIFF;
+        bm.list[C_DIFF_LEAF] = split && rs->sky.kind != PTMI_SKY_NONE ? L_DIFF : L_G_DIFF;
+        bm.list[C_GLASS] = L_G_GLASS; bm.list[C_REFL] = L_G_REFL; bm.list[C_MID] = L_G_MID; bm.list[C_EMIT] = L_G_EMIT;
+        bm.list[C_OTHER] = L_G_OTHER;
+    }
     DevScene sc{};
     sc.uvs = rs->d_uvs; sc.tex = rs->d_tex; sc.tex_pixels = rs->d_tex_pixels; sc.ntex = rs->ntex;
-    sc.stri = rs->d_stri; sc.ntris = (uint32_t)(ctx->tri_idx.size() / 3); sc.nmats = rs->nmats;
+    sc.stri = rs->d_stri; sc.tri_class = rs->d_tri_class; sc.ntris = (uint32_t)(ctx->tri_idx.size() / 3); sc.nmats = rs->nmats;
     sc.mats = rs->d_mats; sc.emissive = rs->d_emissive; sc.nemissive = rs->nemissive;
     sc.lights = rs->d_lights; sc.nlights = rs->nlights; sc.sky = rs->sky; sc.sky_img = rs->d_sky_img;
     sc.bh = rs->bh; sc.has_bh = rs->has_bh;
@@ -1553,7 +2159,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         }
         auto enqueue_batch = [&](Lane &ln, int slot) -> int {
             for (int k = 0; k < iters_per_batch; ++k) {
-                int r = enqueue_iteration(ctx, ln.pl, sc, ln.ra, ln.total, ln.cur, ln.st);
+                int r = enqueue_iteration(ctx, ln.pl, sc, ln.ra, bm, ln.total, ln.cur, ln.st);
                 if (r) return r;
                 ln.cur ^= 1;
             }
@@ -1579,7 +2185,8 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
                 if (!ln.active) continue;
                 PTMI_HIP(ctx, hipEventSynchronize(ln.ev[slot]));
                 const unsigned long long *hc = ln.hc + (size_t)slot * qc_words;
-                const unsigned long long left = hc[(QC_EXT0 + cur_then[l]) * QC_STRIDE] + hc[(QC_SHP0 + cur_then[l]) * QC_STRIDE];
+                const unsigned long long left = hc[(QC_EXT0 + cur_then[l]) * QC_STRIDE] + hc[(QC_SHP0 + cur_then[l]) * QC_STRIDE] +
+                                                hc[(QC_SHA0 + cur_then[l]) * QC_STRIDE];
                 if (left == 0 && hc[QC_NEXT * QC_STRIDE] >= ln.total) ln.active = false;
             }
         }

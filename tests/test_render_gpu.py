@@ -400,9 +400,10 @@ def test_render_profile_adds_up_and_changes_nothing(gpu_ctx):
     parts = [prof[k] for k in ("prepare_ms", "generate_ms", "extend_ms", "connect_ms", "shade_ms", "accumulate_ms")]
     assert all(v > 0.0 for v in parts), prof
     assert sum(parts) <= wall_ms, (prof, wall_ms)
-    # per iteration: prepare, generate, extend, connect, shade (the shared context forces the vote-scheduled kernels, so
-    # one traversal kernel each); per call: the start-of-call kernel and accumulate
-    assert prof["iterations"] >= 4 and prof["launches"] == 5 * prof["iterations"] + 2, prof
+    # per iteration: prepare, generate, extend, connect (the shared context forces the vote-scheduled kernels, so one
+    # traversal kernel each), and shade's four (binning + the three class kernels); per call: the start-of-call kernel
+    # and accumulate
+    assert prof["iterations"] >= 4 and prof["launches"] == 8 * prof["iterations"] + 2, prof
     assert r.profile()["launches"] == 0          # switched off and reset
 
 

@@ -352,14 +352,11 @@ def test_more_launches_in_flight_than_cursor_lines(gpu_ctx):
     O, D = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
     T = torch.full((o.shape[0],), 1000.0, dtype=torch.float32, device=dev)
     streams = [torch.cuda.Stream(dev) for _ in range(3)]
-    torch.cuda.synchronize()
-    outs = []
-    for k in range(150):
-        P = torch.full((o.shape[0],), -7, dtype=torch.int32, device=dev)
-        t = torch.full((o.shape[0],), -1.0, dtype=torch.float32, device=dev)
-        torch.cuda.synchronize() if k == 0 else None
+    outs = [(torch.full((o.shape[0],), -7, dtype=torch.int32, device=dev), torch.full((o.shape[0],), -1.0, dtype=torch.float32, device=dev))
+            for _ in range(150)]
+    torch.cuda.synchronize()                    # the fills ran on torch's stream, the launches go to three others
+    for k, (P, t) in enumerate(outs):
         bvh.CheckIntersectionDevice(O, D, T, P, t, streams[k % 3].cuda_stream)
-        outs.append((P, t))
     torch.cuda.synchronize()
     for P, t in outs[1:]:
         assert torch.equal(P, outs[0][0]) and torch.equal(t.view(torch.int32), outs[0][1].view(torch.int32))

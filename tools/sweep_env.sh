@@ -1,5 +1,6 @@
 #!/bin/bash
-# sweep env-var knobs of the extend kernel: each argument is a space-separated "K=V K=V" set
-for cfg in "$@"; do
-  env $cfg timeout -k 10 300 python -u bench.py --steps 5 --warmup 1 --no-render --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$cfg: Mrays/s', d['value'], 'kernel_ms', d['roofline']['kernel_ms'])" || exit 1
+# usage: tools/sweep_env.sh VAR "v1 v2 ..." [bench_render args]   -- one timed frame per value
+VAR=$1; VALS=$2; shift 2
+for v in $VALS; do
+  echo "== $VAR=$v"; env $VAR=$v timeout -k 10 200 python3 tools/bench_render.py "$@" 2>&1 | grep -E "Msamples|profile" || exit 1
 done
