@@ -44,23 +44,30 @@ __device__ __forceinline__ void lds_barrier() { __asm__ volatile("s_waitcnt lgkm
 // LDS ([word][thread]) from the queue entry of a pending call, or loads it there with eight 16-byte loads when a
 // child returns to it, works on it there and writes it back only when the path parks under a child.
 enum {
+    // first 64-byte sector: what a frame that only waits for its one child (or its shadow rays) is finished with
     F_BB = 0,                                                              // bounces | bounceIndex << 16 | flags << 24 (inputs of TraceRay, :15)
     F_SP = 1,                                                              // sample counter of the GI / reflection loop | phase << 24
-    F_MAT = 2, F_ENERGY = 3, F_LN = 4,
-    F_RO = 7, F_RD = 10, F_T = 13, F_PRIM = 14,                            // the hit being shaded
-    F_DG = 15,                                                             // doppler * gravity
-    F_DIFF = 16,                                                           // diffuse component; until HandleDiffuseMaterial's final sum: its direct lighting
-    F_REFR = 19, F_ALBEDO = 22, F_SUM = 25,
-    F_PDIRECT = 28,                                                        // the CALLER's direct lighting, summed from the shadow terms this call carried
+    F_MAT = 2,
+    F_DG = 3,                                                              // doppler * gravity
+    F_ALBEDO = 4,
+    F_PDIRECT = 7,                                                         // the CALLER's direct lighting, summed from the shadow terms this call carried
+    F_DIFF = 10,                                                           // diffuse component; until HandleDiffuseMaterial's final sum: its direct lighting
+    F_REFR = 13,
+    // second sector: the running sum of the GI / reflection rays and what re-derives the hit for the next one
+    F_SUM = 16, F_ENERGY = 19, F_LN = 20,
+    F_RO = 23, F_RD = 26, F_T = 29, F_PRIM = 30,                           // the hit being shaded
     // F_ALBEDO / F_MAT: what HandleDiffuseMaterial's final sum needs of the hit (textured albedo, material), kept in the
     // frame so that a frame popped by a returning child does not gather its triangle record again.
     // A frame is one 128-byte line in memory (32 words, the last one unused) and FRW words of LDS while it is on top.
+    // A SHORT frame (PH_SHORT in its phase byte) has only its first sector in memory: shade_diff_kernel parks its
+    // frames that way when scatterRays == 1 -- the sum is zero and no second ray will ever need the hit again.
     NF = 31, FRW = 31
 };
 // FL_ANC: a frame below this call waits for its refraction subtree (PH_REFR_WAIT); inherited by every child
-enum { FL_SPECULAR = 1, FL_FLIPPED = 2, FL_ANC = 4 };
+// FL_SHORT (records only): the record has no second sector -- lastSurfaceNormal is {} and no terms arrive (a fresh sample)
+enum { FL_SPECULAR = 1, FL_FLIPPED = 2, FL_ANC = 4, FL_SHORT = 8 };
 // what the top frame is waiting for
-enum { PH_EXTEND = 0, PH_REFR_WAIT = 1, PH_SHADOW_WAIT = 2, PH_GI_WAIT = 3, PH_REFL_WAIT = 4 };
+enum { PH_EXTEND = 0, PH_REFR_WAIT = 1, PH_SHADOW_WAIT = 2, PH_GI_WAIT = 3, PH_REFL_WAIT = 4, PH_MASK = 0x7F, PH_SHORT = 0x80 };
 enum { HS_MISS = 0, HS_HIT = 1, HS_HORIZON = 2 };
 // queue counters: each on a 128-byte line of its own (atomics on one line serialise at ~12 ns each whatever word
 // they address), the double-buffered queues with one counter per buffer
@@ -193,7 +200,7 @@ struct Pool {
     float4 *q_shpath[2];                 // paths waiting for their shadow rays, 2 x float4 per entry: lean ones from the front, the others from the back
     float4 *q_shp_sh[2];                 // ... their shadow terms: nshadow x (term.xyz, bits(position of the ray))
     float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, -)
-    uint32_t *q_sray_occ;                // connect's answers, by position in the shadow-ray queue (0 free, 1 occluded)
+    uint8_t *q_sray_occ;                 // connect's answers, by position in the shadow-ray queue (0 free, 1 occluded)
     uint32_t *q_free;                    // slots that finished in the last shade pass
     unsigned long long *qcnt;            // QC_COUNT counters, QC_STRIDE words apart
     IterArgs *it;                        // this iteration's arguments (iter_prep_kernel)
@@ -308,18 +315,49 @@ __device__ __forceinline__ void wave_store_lines(const float *col, int stride, f
     }
 }
 
+enum { XCH_WORDS = 16 };
+// Half a line per lane through a [16][256] exchange area: lane 8 g + 4 r + q writes quarter q of the half-lines of lanes
+// 8 g + r, 8 g + 2 + r, ... (every store instruction covers sixteen 64-byte sectors).  The lane's 16 words of this half
+// are in its column already.
+__device__ __forceinline__ void wave_store_half(const float *col, float4 *dst, int half) {
+    const unsigned long long m_st = __ballot(dst != nullptr);
+    if (!m_st) return;
+    const int lane = threadIdx.x & 63, grp = lane & ~7, r = (lane >> 2) & 1, q = lane & 3;
+    const uint32_t lo = (uint32_t)(uintptr_t)dst, hi = (uint32_t)((uintptr_t)dst >> 32);
+    const float *base = col - lane;
+    for (int i = 0; i < 4; ++i) {
+        const int src = grp + 2 * i + r;
+        const uint32_t slo = (uint32_t)__shfl((int)lo, src), shi = (uint32_t)__shfl((int)hi, src);
+        if (m_st >> src & 1ull) {
+            float4 *d = (float4 *)(((uintptr_t)shi << 32) | (uintptr_t)slo);
+            const float *c = base + src;
+            d[4 * half + q] = make_float4(c[(4 * q) * 256], c[(4 * q + 1) * 256], c[(4 * q + 2) * 256], c[(4 * q + 3) * 256]);
+        }
+    }
+}
+
 // What extend tells the binning about an entry (C_*): tracer.go's branches in the order TraceRay takes them -- the
 // entry test (:16), miss / horizon (:250-263), glass (:49), the accretion disk (:95), reflectivity (:116-163), an
 // emitter seen by an indirect ray (:461-465), and the plain diffuse surface with or without bounces left (:622).
-__device__ __forceinline__ uint32_t classify(int status, int prim, uint32_t ctx, const uint8_t *__restrict__ tri_class) {
+__device__ __forceinline__ uint32_t classify(int status, uint32_t tc, uint32_t ctx) {      // tc = TC_* bits of the hit triangle
     if (status != HS_HIT || (ctx & CTX_FAIL)) return (ctx & CTX_ANC) ? C_RET_ANC : C_RET;
-    const uint32_t tc = tri_class[prim];
     if (tc & TC_GLASS) return C_GLASS;
     if (tc & TC_ACCR) return C_OTHER;
     if (tc & TC_REFL) return C_REFL;
     if (tc & TC_MID) return C_MID;
     if ((tc & TC_EMIT) && (ctx & CTX_BI)) return C_EMIT;
     return (ctx & CTX_B0) ? C_DIFF_LEAF : C_DIFF;
+}
+// ptmi_upload_scene writes a triangle's TC_* bits into the spare fourth word of its packed traversal record, so the
+// vote-scheduled walk has them at hand with the hit (a gather by primitive at store time stalls the whole wave's
+// refill step: extend +12 % when measured)
+__global__ __launch_bounds__(256) void patch_tri_class_kernel(float4 *tris, uint32_t nrecords, const uint8_t *__restrict__ tri_class, uint32_t ntris) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrecords) return;
+    float4 v = tris[3 * (size_t)r + 2];
+    const uint32_t prim = f2u(v.y);
+    v.w = u2f(prim < ntris ? (uint32_t)tri_class[prim] : 0u);
+    tris[3 * (size_t)r + 2] = v;
 }
 // CTX_* bits of a pending call with these arguments
 __device__ __forceinline__ uint32_t call_ctx(int bounces, int bindex, float energy, uint32_t flags) {
@@ -331,11 +369,11 @@ __device__ __forceinline__ uint32_t pack_call(int depth, uint32_t trk_len, int b
 }
 
 // A fresh sample is a pending call and nothing else: one record at the end of the extend queue (no atomic: entry
-// gen_base + i), written as whole lines; its slot comes from the free list.
+// gen_base + i), written as whole sectors; its slot comes from the free list.
 __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, int cur) {
     // the 256 records a workgroup writes per trip are contiguous, so they are put together in LDS ([word][thread]) and
     // written out as whole lines (per-thread 16-byte stores 128 bytes apart reach 3.2 TB/s)
-    __shared__ float s_rec[20 * 256];
+    __shared__ float s_rec[16 * 256];
     const uint32_t n = pl.it->gen_n, q_base = pl.it->gen_base;
     const unsigned long long first_sample = pl.it->first_sample;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -365,13 +403,12 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, i
             w[R_HIT * 256] = 0.0f; w[R_T * 256] = 0.0f;
             w[R_KEY * 256] = u2f(rng.key); w[R_CTR * 256] = u2f(rng.ctr);
             w[R_PACK * 256] = u2f(pack_call(0, 1u, ra.p.bounces, 0));                                  // depth 0, tracker {1.0}
-            w[R_FLAGS * 256] = u2f(0u);
+            w[R_FLAGS * 256] = u2f((uint32_t)FL_SHORT);             // lastSurfaceNormal {} and no terms: the first sector is the record
             w[R_ENERGY * 256] = 1.0f; w[R_TRK0 * 256] = 1.0f;
-            w[R_LN * 256] = 0.0f; w[(R_LN + 1) * 256] = 0.0f; w[(R_LN + 2) * 256] = 0.0f; w[R_TERMS * 256] = 0.0f;
             dst = rec_at(pl, cur, (size_t)q_base + i);
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own LDS writes, before its lanes read them
-        wave_store_lines(s_rec + threadIdx.x, 256, dst, 20);
+        wave_store_half(s_rec + threadIdx.x, dst, 0);
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
@@ -422,7 +459,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
             }
         }
         ((float2 *)rec)[R_HIT / 2] = make_float2(u2f((uint32_t)status << 30 | ((uint32_t)prim & 0x3FFFFFFFu)), t);
-        pl.q_cls[i] = (uint8_t)classify(status, prim, f2u(qa.w) >> CTX_SHIFT, sc.tri_class);
+        pl.q_cls[i] = (uint8_t)classify(status, status == HS_HIT ? (uint32_t)sc.tri_class[prim] : 0u, f2u(qa.w) >> CTX_SHIFT);
         // shade reads the ray from the record: the origin of a hit (tracer.go:37 adds t to the CURRENT origin) and,
         // for a curved ray, the direction it ended with (the sky lookup of a miss, :260-263)
         if (CURVED) {
@@ -449,15 +486,14 @@ __device__ __forceinline__ uint32_t vote_chunk(uint64_t n, uint32_t chunk_max) {
 }
 struct ExtTag { uint32_t entry, ctx; };
 template <int STACK>
-__global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Pool pl, const uint8_t *__restrict__ tri_class, RenderArgs ra,
-                                                                  int cur, uint32_t vote_from, unsigned long long *counters, int refill_min,
+__global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Pool pl, RenderArgs ra, int cur, uint32_t vote_from, unsigned long long *counters, int refill_min,
                                                                   int tri_bias, uint32_t chunk_max) {
     __shared__ uint32_t smem[STACK * WAVE];
     const uint32_t n = pl.it->n_ext;
     if (n < vote_from || (uint64_t)blockIdx.x * WAVE >= n) return;          // the one-shot kernel takes small launches
     const float step = ra.p.step_size;
     TravCounters cnt;
-    vote_walk<WAVE, false, false, ExtTag>(
+    vote_walk<WAVE, false, false, ExtTag, true>(
         bvh, smem + threadIdx.x, n, pl.qcnt + (size_t)QC_CURSOR_EXT * QC_STRIDE, refill_min, tri_bias, vote_chunk(n, chunk_max), cnt,
         [&](uint64_t idx, NextRay &nx, ExtTag &tag) {
             const float4 *rec = rec_at(pl, cur, idx);
@@ -469,7 +505,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Po
             const bool hit = r.best >= 0;
             ((float2 *)rec_at(pl, cur, tag.entry))[R_HIT / 2] =
                 make_float2(u2f((uint32_t)(hit ? HS_HIT : HS_MISS) << 30 | ((uint32_t)r.best & 0x3FFFFFFFu)), hit ? r.best_t : 0.0f);
-            pl.q_cls[tag.entry] = (uint8_t)classify(hit ? HS_HIT : HS_MISS, r.best, tag.ctx, tri_class);
+            pl.q_cls[tag.entry] = (uint8_t)classify(hit ? HS_HIT : HS_MISS, r.best_aux, tag.ctx);
         });
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)n);
 }
@@ -552,7 +588,7 @@ __device__ __forceinline__ uint64_t sray_total(const ShadowCounts &sn) {
 
 // One-shot waves on a fixed grid, for launches too small for the vote-scheduled kernel.
 template <int STACK>
-__global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool pl, uint32_t vote_from, unsigned long long *counters) {
+__global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool pl, int cur, uint32_t vote_from, unsigned long long *counters) {
     __shared__ uint32_t smem[STACK * WAVE];
     const ShadowCounts sn = pl.it->sray;
     const uint64_t n = sray_total(sn);
@@ -563,7 +599,7 @@ __global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool p
         const size_t e = sray_entry(pl, sn, j);
         const float4 a = pl.q_sray_a[e], bb = pl.q_sray_b[e];
         TravCounters tc;
-        pl.q_sray_occ[e] = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc) ? 1u : 0u;
+        pl.q_sray_occ[e] = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc) ? 1 : 0;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
 }
@@ -571,7 +607,7 @@ __global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool p
 // connect: persistent waves walking vote-scheduled single steps (vote_walk, trav_device.hpp), shadow rays dealt in
 // chunks from one cursor over the buckets laid end to end (a chunk is nearly always of one kind).
 template <int STACK>
-__global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, Pool pl, uint32_t vote_from, unsigned long long *counters,
+__global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, Pool pl, int cur, uint32_t vote_from, unsigned long long *counters,
                                                                    int refill_min, int tri_bias, uint32_t chunk_max) {
     __shared__ uint32_t smem[STACK * WAVE];
     const ShadowCounts sn = pl.it->sray;
@@ -585,7 +621,7 @@ __global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, P
             const float4 a = pl.q_sray_a[e], bb = pl.q_sray_b[e];
             nx.ox = a.x; nx.oy = a.y; nx.oz = a.z; nx.tmax = a.w; nx.dx = bb.x; nx.dy = bb.y; nx.dz = bb.z; pos = (uint32_t)e;
         },
-        [&](uint32_t pos, const RayTrav &r) { pl.q_sray_occ[pos] = r.best ? 1u : 0u; });   // the answer goes beside the ray
+        [&](uint32_t pos, const RayTrav &r) { pl.q_sray_occ[pos] = r.best ? 1 : 0; });   // the answer goes beside the ray (one byte)
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
 }
 
@@ -737,7 +773,7 @@ __device__ __forceinline__ V3 sum_free_terms(const Pool &pl, uint32_t &pneed, ui
         const float4 v = term(k);
         uint32_t qi = f2u(v.w);
         if (qi >= pl.cap * (uint32_t)pl.nshadow) { err |= ERR_SLOT; qi = 0; }
-        if (pl.q_sray_occ[qi] == 0u) pdirect = add(pdirect, mk(v.x, v.y, v.z));
+        if (pl.q_sray_occ[qi] == 0) pdirect = add(pdirect, mk(v.x, v.y, v.z));
     }
     return pdirect;
 }
@@ -838,7 +874,10 @@ __device__ __forceinline__ TailPos tail_reserve(const Pool &pl, int cur, float *
 __device__ __forceinline__ size_t shp_entry(const Pool &pl, uint32_t pos, bool back) { return back ? (size_t)pl.cap - 1 - pos : (size_t)pos; }
 
 // Writes a path's staged shadow rays into their buckets and hands back the term (contribution, queue position) of each
-// through put(k, term).  s_ray = the staging area ([word][thread] columns of 256), tid = this thread's column.
+// through put(k, term).  s_ray = the staging area ([word][thread] columns of 256).
+// (Tried: the ray carries the address of its term and connect stores the answer there, so that the summing visit needs
+// no gather -- shade -5 ms per C3 frame, connect +9: a 4-byte store into a record of its own sector is a read-modify-
+// write of that sector, where the answers by ray position are nearly sequential.)
 template <typename Put>
 __device__ __forceinline__ void flush_shadow_rays(const Pool &pl, const float *s_ray, uint32_t need_out, const TailPos &tp, V3 sh_o, V3 sh_eo, Put put) {
     uint32_t pos_last = tp.ray_last;
@@ -913,33 +952,36 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
             const V3 direct = sum_free_terms(pl, pneed, err, [&](int t) { return terms[t]; });
             // the parked frame: HandleDiffuseMaterial's final sum with no GI rays (bounces <= 0), then TraceRay's (:218-223)
             const float4 *f = frame_at(depth);
-            const float4 f0 = f[0], f3 = f[3], f4 = f[4], f5 = f[5], f6 = f[6], f7 = f[7];
+            const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
             const uint32_t bb = f2u(f0.x), sp = f2u(f0.y);
             uint32_t fmat = f2u(f0.z);
             if (fmat >= sc.nmats) { err |= ERR_MAT; fmat = 0; }
             const int bounces = (int)(int16_t)(bb & 0xFFFFu), bindex = (int)((bb >> 16) & 0xFFu);
-            if ((sp >> 24) != (uint32_t)PH_SHADOW_WAIT) err |= ERR_PHASE;
+            if (((sp >> 24) & PH_MASK) != (uint32_t)PH_SHADOW_WAIT) err |= ERR_PHASE;
             if (bounces > 0) err |= ERR_CLASS;
-            const V3 refr = mk(f4.w, f5.x, f5.y), albedo = mk(f5.z, f5.w, f6.x), gi = mk(f6.y, f6.z, f6.w);
+            V3 gi = mk(0, 0, 0);
+            if (!(sp >> 24 & PH_SHORT)) { const float4 f4 = f[4]; gi = mk(f4.x, f4.y, f4.z); }
+            const V3 albedo = mk(f1.x, f1.y, f1.z), refr = mk(f3.y, f3.z, f3.w);
             const V3 fin = diffuse_final(sc, ra, fmat, bounces, bindex, direct, gi, albedo);
             diffuse_events++;
-            ret = combine_components(fin, mk(0, 0, 0), refr, f3.w);
-            pd = mk(f7.x, f7.y, f7.z);
+            ret = combine_components(fin, mk(0, 0, 0), refr, f0.w);
+            pd = mk(f1.w, f2.x, f2.y);
         }
         // unwind: hand `ret` to the caller frame, and with it the caller's direct lighting this call carried
         while (depth > 0 && !err) {
             depth--;
             const float4 *f = frame_at(depth);
-            const float4 f0 = f[0], f3 = f[3], f4 = f[4], f5 = f[5], f6 = f[6], f7 = f[7];
+            const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
             const uint32_t bb = f2u(f0.x), sp = f2u(f0.y);
             uint32_t fmat = f2u(f0.z);
             if (fmat >= sc.nmats) { err |= ERR_MAT; fmat = 0; }
             const int bounces = (int)(int16_t)(bb & 0xFFFFu), bindex = (int)((bb >> 16) & 0xFFu);
-            const uint32_t ph = sp >> 24, s = sp & 0xFFFFFFu;
-            const float dg = f3.w;
-            V3 fdiff = mk(f4.x, f4.y, f4.z);
-            const V3 refr = mk(f4.w, f5.x, f5.y), albedo = mk(f5.z, f5.w, f6.x);
-            V3 fsum = mk(f6.y, f6.z, f6.w);
+            const uint32_t ph = (sp >> 24) & PH_MASK, s = sp & 0xFFFFFFu;
+            const float dg = f0.w;
+            V3 fdiff = mk(f2.z, f2.w, f3.x);
+            const V3 refr = mk(f3.y, f3.z, f3.w), albedo = mk(f1.x, f1.y, f1.z);
+            V3 fsum = mk(0, 0, 0);
+            if (!(sp >> 24 & PH_SHORT)) { const float4 f4 = f[4]; fsum = mk(f4.x, f4.y, f4.z); }
             if (s != 0u) err |= ERR_CLASS;                                  // scatterRays == 1: the frame waits for its only ray
             if (ph == (uint32_t)PH_GI_WAIT) {                               // :640-647, :658-667
                 fdiff = pd;                                                 // the first scattered ray carried this frame's shadow terms
@@ -954,7 +996,7 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
             } else {
                 err |= ERR_PHASE;
             }
-            pd = mk(f7.x, f7.y, f7.z);
+            pd = mk(f1.w, f2.x, f2.y);
         }
         if (err) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)err); ret = mk(0, 0, 0); }
         float *o = pl.out + 3 * (size_t)(sid < ra.total ? sid : 0);
@@ -973,27 +1015,6 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
 // LDS: the staged shadow rays ([word][thread], as in the general kernel), reused as the exchange area of the whole-line
 // stores once the rays are out: 16 words per thread at least, 20 with three shadow-ray kinds -- four workgroups per CU
 // and more where the general kernel has three.
-enum { XCH_WORDS = 16 };
-// Half a line per lane through a [16][256] exchange area: lane 8 g + 4 r + q writes quarter q of the half-lines of lanes
-// 8 g + r, 8 g + 2 + r, ... (every store instruction covers sixteen 64-byte sectors).  The lane's 16 words of this half
-// are in its column already.
-__device__ __forceinline__ void wave_store_half(const float *col, float4 *dst, int half) {
-    const unsigned long long m_st = __ballot(dst != nullptr);
-    if (!m_st) return;
-    const int lane = threadIdx.x & 63, grp = lane & ~7, r = (lane >> 2) & 1, q = lane & 3;
-    const uint32_t lo = (uint32_t)(uintptr_t)dst, hi = (uint32_t)((uintptr_t)dst >> 32);
-    const float *base = col - lane;
-    for (int i = 0; i < 4; ++i) {
-        const int src = grp + 2 * i + r;
-        const uint32_t slo = (uint32_t)__shfl((int)lo, src), shi = (uint32_t)__shfl((int)hi, src);
-        if (m_st >> src & 1ull) {
-            float4 *d = (float4 *)(((uintptr_t)shi << 32) | (uintptr_t)slo);
-            const float *c = base + src;
-            d[4 * half + q] = make_float4(c[(4 * q) * 256], c[(4 * q + 1) * 256], c[(4 * q + 2) * 256], c[(4 * q + 3) * 256]);
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void shade_diff_kernel(Pool pl, DevScene sc, RenderArgs ra, int cur, unsigned long long *counters) {
     const uint32_t n = (uint32_t)pl.qcnt[(size_t)(QC_LIST + L_DIFF) * QC_STRIDE];
     if (blockIdx.x * blockDim.x >= n) return;
@@ -1017,7 +1038,8 @@ __global__ __launch_bounds__(256) void shade_diff_kernel(Pool pl, DevScene sc, R
         uint32_t e = pl.q_idx[(size_t)L_DIFF * pl.cap + i];
         if (e >= pl.it->n_ext) { err |= ERR_QUEUE; e = 0; }
         const float4 *rec = rec_at(pl, cur, e);
-        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        const float4 r4 = (f2u(r3.y) & FL_SHORT) ? make_float4(0, 0, 0, 0) : rec[4];
         uint32_t slot = f2u(r0.w) & (uint32_t)SLOT_MASK;
         if (slot >= pl.cap) { err |= ERR_SLOT; slot = 0; }
         sid = f2u(r1.w);
@@ -1028,7 +1050,7 @@ __global__ __launch_bounds__(256) void shade_diff_kernel(Pool pl, DevScene sc, R
         uint32_t trk_len = (packed >> 8) & 0xFFu;
         if ((int)trk_len > pl.ntrk) { err |= ERR_DEPTH; trk_len = 0; }
         const int bounces = (int)(int8_t)((packed >> 16) & 0xFFu), bindex = (int)(packed >> 24);
-        const uint32_t flags = fword & 0xFFu & ~(uint32_t)FL_FLIPPED;
+        const uint32_t flags = fword & 0xFFu & ~(uint32_t)(FL_FLIPPED | FL_SHORT);
         uint32_t pneed = fword >> 8;
         const float energy = r3.z;
         trk0 = r3.w;
@@ -1082,7 +1104,7 @@ __global__ __launch_bounds__(256) void shade_diff_kernel(Pool pl, DevScene sc, R
         rng_key = rng.key; rng_ctr = rng.ctr;
         // ---- the frame (F_*)
         fw[F_BB] = u2f(((uint32_t)bounces & 0xFFFFu) | ((uint32_t)bindex & 0xFFu) << 16 | flags << 24);
-        fw[F_SP] = u2f(phase << 24);
+        fw[F_SP] = u2f((phase | (ra.p.scatter_rays == 1 ? (uint32_t)PH_SHORT : 0u)) << 24);
         fw[F_MAT] = u2f(h.mat); fw[F_ENERGY] = energy;
         fw[F_LN] = ln.x; fw[F_LN + 1] = ln.y; fw[F_LN + 2] = ln.z;
         fw[F_RO] = cur_o.x; fw[F_RO + 1] = cur_o.y; fw[F_RO + 2] = cur_o.z;
@@ -1128,9 +1150,10 @@ __global__ __launch_bounds__(256) void shade_diff_kernel(Pool pl, DevScene sc, R
     // staged rays are out; every lane only touches its own wave's columns)
     __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float *col = s_ray + tid;
-    auto store_line = [&](float4 *dst, auto word) {
+    auto store_line = [&](float4 *dst, int halves, auto word) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            if (half >= halves) break;
 #pragma unroll
             for (int k = 0; k < 16; ++k) col[k * 256] = word(16 * half + k);
             __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1138,8 +1161,8 @@ __global__ __launch_bounds__(256) void shade_diff_kernel(Pool pl, DevScene sc, R
             __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     };
-    store_line(frame_dst, [&](int k) { return fw[k]; });
-    store_line(rec_dst, [&](int k) { return k < R_TERMS ? rw[k] : (k < R_TERMS + 12 ? tw[k - R_TERMS] : 0.0f); });
+    store_line(frame_dst, ra.p.scatter_rays == 1 ? 1 : 2, [&](int k) { return fw[k]; });      // a SHORT frame is its first sector
+    store_line(rec_dst, 2, [&](int k) { return k < R_TERMS ? rw[k] : (k < R_TERMS + 12 ? tw[k - R_TERMS] : 0.0f); });
 }
 
 // ------------------------------------------------------------------------------------------ shade: the general kernel
@@ -1211,7 +1234,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (e >= pl.it->n_ext) { err |= ERR_QUEUE; e = 0; }
             const float4 *rec = rec_at(pl, cur, e);
             qa = rec[0]; qb = rec[1];
-            const float4 r2 = rec[2], r3 = rec[3], r4 = rec[4];
+            const float4 r2 = rec[2], r3 = rec[3];
+            const float4 r4 = (f2u(r3.y) & FL_SHORT) ? make_float4(0, 0, 0, 0) : rec[4];
             slot = f2u(qa.w) & (uint32_t)SLOT_MASK;
             sid = f2u(qb.w);
             const uint32_t hitword = f2u(r2.x);
@@ -1262,7 +1286,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         auto load_frame = [&](int dep) {
             const float4 *f = frames + (size_t)dep * 8;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const float4 v = f[k]; FW(4 * k) = v.x; FW(4 * k + 1) = v.y; FW(4 * k + 2) = v.z; if (4 * k + 3 < FRW) FW(4 * k + 3) = v.w; }
+            for (int k = 0; k < 4; ++k) { const float4 v = f[k]; FW(4 * k) = v.x; FW(4 * k + 1) = v.y; FW(4 * k + 2) = v.z; FW(4 * k + 3) = v.w; }
+            if (f2u(FW(F_SP)) >> 24 & PH_SHORT) {   // only the first sector is in memory: the sum is zero, the hit is never needed again
+                FW(F_SUM) = 0.0f; FW(F_SUM + 1) = 0.0f; FW(F_SUM + 2) = 0.0f;
+                return;
+            }
+#pragma unroll
+            for (int k = 4; k < 8; ++k) { const float4 v = f[k]; FW(4 * k) = v.x; FW(4 * k + 1) = v.y; FW(4 * k + 2) = v.z; if (4 * k + 3 < FRW) FW(4 * k + 3) = v.w; }
         };
         // A frame is parked (under a child, or to wait for its shadow rays) only as the LAST thing a visit does, so the
         // store is deferred to the end of the kernel, where the whole wave writes the parked frames together: 8 lanes per
@@ -1288,7 +1318,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         auto f_flags = [&]() -> uint32_t { return FU(F_BB) >> 24; };
         auto set_flags = [&](uint32_t fl) { FU_SET(F_BB, (FU(F_BB) & 0xFFFFFFu) | fl << 24); };
         auto f_s = [&]() -> int { return (int)(FU(F_SP) & 0xFFFFFFu); };
-        auto f_phase = [&]() -> uint32_t { return FU(F_SP) >> 24; };
+        auto f_phase = [&]() -> uint32_t { return (FU(F_SP) >> 24) & PH_MASK; };
         auto set_s = [&](int s) { FU_SET(F_SP, (FU(F_SP) & 0xFF000000u) | ((uint32_t)s & 0xFFFFFFu)); };
         auto set_phase = [&](uint32_t ph) { FU_SET(F_SP, (FU(F_SP) & 0xFFFFFFu) | ph << 24); };
         // RefractiveIndexTracker.indices: entry 0 in a register (it travels with the path), the rest in Pool::trk
@@ -1315,7 +1345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         bool have_hit = false;
         // entry: a pending call starts from its arguments, a parked frame comes back with its shadow answers
         if (pending) {
-            FU_SET(F_BB, ((uint32_t)in_bounces & 0xFFFFu) | ((uint32_t)in_bindex & 0xFFu) << 16 | (in_flags & ~(uint32_t)FL_FLIPPED) << 24);
+            FU_SET(F_BB, ((uint32_t)in_bounces & 0xFFFFu) | ((uint32_t)in_bindex & 0xFFu) << 16 | (in_flags & ~(uint32_t)(FL_FLIPPED | FL_SHORT)) << 24);
             FW(F_ENERGY) = in_energy;
             FW(F_LN) = in_ln.x; FW(F_LN + 1) = in_ln.y; FW(F_LN + 2) = in_ln.z;
             FV_SET(F_PDIRECT, pdirect);                                     // handed back to the caller when this call returns
@@ -1758,6 +1788,13 @@ extern "C" int ptmi_upload_scene(ptmi_ctx *ctx, const PtMaterial *materials, uin
         }
         for (uint64_t t = 0; t < ntris; ++t) tc[t] = mc[tri_material[t]];
         if ((rc = upload(ctx, rs->d_tri_class, tc.data(), tc.size()))) return rc;
+        // ... and into the packed traversal records (classify: the vote-scheduled extend reads them from there)
+        const uint32_t nrec = (uint32_t)ctx->packed_tris;
+        if (nrec) {
+            hipLaunchKernelGGL(patch_tri_class_kernel, dim3((nrec + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_tris, nrec, rs->d_tri_class, (uint32_t)ntris);
+            PTMI_HIP(ctx, hipGetLastError());
+            PTMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
     }
     if ((rc = upload(ctx, rs->d_mats, materials, (size_t)nmaterials))) return rc;
     if ((rc = upload(ctx, rs->d_lights, lights, (size_t)nlights))) return rc;
@@ -1836,7 +1873,7 @@ static uint64_t pool_bytes_per_path(int bounces, int nlights, bool curved) {
     // frames + tracker history + shadow-ray queue (ray, answer) and the shadow terms beside the shadow-wait queue (double
     // buffered) + extend queue (records, double buffered; class byte; index lists) + shadow-wait queue (double
     // buffered) + free list
-    return 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (32 + 4 + 16 * 2) * nshadow + 16 * (uint64_t)record_quads((int)nshadow, curved) * 2 +
+    return 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (32 + 1 + 16 * 2) * nshadow + 16 * (uint64_t)record_quads((int)nshadow, curved) * 2 +
            1 + 4 * NLIST + 32 * 2 + 4;
 }
 
@@ -1856,7 +1893,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes, bool
         Off &o = of[l];
         o.fr = carve(off, 128 * c * (size_t)nframes); o.trk = carve(off, 4 * c * ntrk);
         o.qs0 = carve(off, 32 * c); o.qs1 = carve(off, 32 * c);
-        o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow); o.occ = carve(off, 4 * c * nshadow);
+        o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow); o.occ = carve(off, c * nshadow);
         o.ss0 = carve(off, 16 * c * nshadow); o.ss1 = carve(off, 16 * c * nshadow);
         o.rec0 = carve(off, 16 * c * rec_q); o.rec1 = carve(off, 16 * c * rec_q);
         o.cls = carve(off, c + BIN_CHUNK); o.idx = carve(off, 4 * c * NLIST);
@@ -1876,7 +1913,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes, bool
         p.rec_q = rec_q; p.rec_inline = record_inline_terms(curved);
         p.fr = (float4 *)(b + o.fr); p.trk = (float *)(b + o.trk);
         p.q_shp_sh[0] = (float4 *)(b + o.ss0); p.q_shp_sh[1] = (float4 *)(b + o.ss1);
-        p.q_sray_occ = (uint32_t *)(b + o.occ);
+        p.q_sray_occ = (uint8_t *)(b + o.occ);
         p.q_rec[0] = (float4 *)(b + o.rec0); p.q_rec[1] = (float4 *)(b + o.rec1);
         p.q_cls = (uint8_t *)(b + o.cls); p.q_idx = (uint32_t *)(b + o.idx);
         p.q_shpath[0] = (float4 *)(b + o.qs0); p.q_shpath[1] = (float4 *)(b + o.qs1);
@@ -1953,7 +1990,7 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
         const unsigned pgrid = (unsigned)std::min<uint64_t>(cap_waves, (uint64_t)ctx->num_cus * per_cu);
         if (most >= vote_from)          // a call this small never has a queue that long: one launch less per iteration
             timed(ctx, PROF_EXTEND, s, [&] {
-                hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, sc.tri_class, ra, cur, vote_from,
+                hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, cur, vote_from,
                                    ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk); });
     }
     if (vote_from > 0) {
@@ -1975,13 +2012,13 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
         const unsigned pgrid = (unsigned)std::min<uint64_t>(ray_waves, (uint64_t)ctx->num_cus * per_cu);
         if (most * (uint64_t)pl.nshadow >= vote_from)
             timed(ctx, PROF_CONNECT, s, [&] {
-                hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, vote_from,
+                hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, cur, vote_from,
                                    ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk); });
     }
     if (vote_from > 0) {
         const unsigned grid = (unsigned)std::min<uint64_t>(ray_waves, ((uint64_t)vote_from + WAVE - 1) / WAVE);
         timed(ctx, PROF_CONNECT, s, [&] {
-            hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, vote_from, ctx->d_counters); });
+            hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, cur, vote_from, ctx->d_counters); });
     }
     // shade: the class bytes extend wrote become index lists, then one kernel per class (all three count as shade time)
     const size_t ray_lds = (size_t)(SRW * pl.nshadow - 1) * 256 * sizeof(float);

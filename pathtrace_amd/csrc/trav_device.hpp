@@ -286,6 +286,7 @@ struct RayTrav {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz;
     float best_t;
     int best;
+    uint32_t best_aux;   // the fourth word of the best triangle's record (AUX walks only: the integrator keeps the material class there)
     uint32_t cur;
     int sp;
     bool exact;          // needs the NaN-exact slab
@@ -295,7 +296,7 @@ __device__ __forceinline__ void trav_init(RayTrav &r, const DevBVH &bvh, float o
                                           float dz, float step) {
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
     r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;        // Inverse() (vec3.go:118-124)
-    r.best_t = step; r.best = -1; r.cur = bvh.root_ref; r.sp = 0;
+    r.best_t = step; r.best = -1; r.best_aux = 0u; r.cur = bvh.root_ref; r.sp = 0;
     r.exact = ray_needs_exact(bvh, ox, oy, oz, r.ix, r.iy, r.iz, step);
 }
 
@@ -343,7 +344,7 @@ __device__ __forceinline__ void vote_inner_step(const DevBVH &bvh, uint32_t *sta
 // dot products are evaluated up front, each operation as the source line writes it, and the early returns of
 // utils.go become one predicate (a NaN fails each `<`/`>` exactly as in the reference).  Scalar f32 on purpose:
 // v_pk_mul/add_f32 issue at half rate on gfx950 (tools/ubench_pk.hip) and need extra moves.
-template <int BLOCK, bool COUNT>
+template <int BLOCK, bool COUNT, bool AUX = false>
 __device__ __forceinline__ void vote_tri_step(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
     const float EPS = (float)1e-6;
     const float ONE_PLUS_EPS = (float)1.000001;
@@ -366,7 +367,10 @@ __device__ __forceinline__ void vote_tri_step(const DevBVH &bvh, uint32_t *stack
     hit = hit && !(v < -EPS || u + v > ONE_PLUS_EPS);                        // :111-113
     hit = hit && !(t <= EPS || t > r.best_t);                                // :118-120 (stepSize = best_t, linear_bvh.go:132)
     if (COUNT) { if (rec != bvh.dummy_tri) cnt.tri++; }
-    if (hit && t < r.best_t && t > 0.0f) { r.best_t = t; r.best = (int)__float_as_uint(r2.y); }   // linear_bvh.go:133-136
+    if (hit && t < r.best_t && t > 0.0f) {                                                        // linear_bvh.go:133-136
+        r.best_t = t; r.best = (int)__float_as_uint(r2.y);
+        if (AUX) r.best_aux = __float_as_uint(r2.w);
+    }
     if (__float_as_uint(r2.z) == 0u) {                  // last record of the leaf
         if (COUNT) cnt.leaf++;
         r.cur = trav_pop<BLOCK>(stack_base, r.sp);
@@ -453,14 +457,14 @@ __device__ __forceinline__ void vote_tri_step_any(const DevBVH &bvh, uint32_t *s
 // Returns the number of rays this lane walked.  The workgroup is one wave.
 struct NextRay { float ox, oy, oz, dx, dy, dz, tmax; };
 
-template <int BLOCK, bool ANY, bool COUNT, typename Tag, typename Fetch, typename Store>
+template <int BLOCK, bool ANY, bool COUNT, typename Tag, bool AUX = false, typename Fetch, typename Store>
 __device__ __forceinline__ uint32_t vote_walk(const DevBVH &bvh, uint32_t *stack_base, uint64_t n, unsigned long long *cursor,
                                               int refill_min, int tri_bias, uint32_t chunk_rays, TravCounters &cnt,
                                               Fetch fetch, Store store) {
     const uint32_t lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     RayTrav r;
-    r.cur = D_REF_DONE; r.exact = false; r.sp = 0; r.best = ANY ? 0 : -1; r.best_t = 0.0f;
+    r.cur = D_REF_DONE; r.exact = false; r.sp = 0; r.best = ANY ? 0 : -1; r.best_t = 0.0f; r.best_aux = 0u;
     r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
     Tag my_tag{}, next_tag{};
     NextRay nx = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -522,7 +526,7 @@ __device__ __forceinline__ uint32_t vote_walk(const DevBVH &bvh, uint32_t *stack
                 if (at_inner) { if (ANY) vote_inner_step_any<BLOCK, COUNT, false>(bvh, stack_base, r, cnt); else vote_inner_step<BLOCK, COUNT, false>(bvh, stack_base, r, cnt); }
             }
         } else {
-            if (at_tri) { if (ANY) vote_tri_step_any<BLOCK, COUNT>(bvh, stack_base, r, cnt); else vote_tri_step<BLOCK, COUNT>(bvh, stack_base, r, cnt); }
+            if (at_tri) { if (ANY) vote_tri_step_any<BLOCK, COUNT>(bvh, stack_base, r, cnt); else vote_tri_step<BLOCK, COUNT, AUX>(bvh, stack_base, r, cnt); }
         }
     }
     return nrays;
