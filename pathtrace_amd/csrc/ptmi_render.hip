@@ -123,15 +123,15 @@ static_assert(sizeof(IterArgs) <= 128, "IterArgs is one line");
 //   gathered record must not share its sectors with another entry (a [field][entry] layout read through a permutation
 //   fetches every sector about twice).  Words:
 //      0-2  ray origin             3  slot | CTX_* << 26          4-6  ray direction       7  sample id
-//      8    hit: status << 30 | primitive (30 bits)      9  t     -- written by extend (one 8-byte store)
+//      8-9  spare (extend's answer -- status << 30 | primitive, t -- goes to a dense array beside the queue, q_hit: an
+//           8-byte store into a record is a read-modify-write of its sector, extend +12 % when measured)
 //     10    RNG key     11  RNG counter
 //     12    depth | tracker length << 8 | bounces << 16 (int8) | bounceIndex << 24
 //     13    flags | shadow-term mask << 8       14  energy       15  tracker entry 0      16-18  lastSurfaceNormal
 //     19..  shadow terms of the caller's rays, 4 words each (term.xyz, position of the ray in the shadow-ray queue):
 //           the first REC_INLINE (3; curved rays 2) in words 19.., the others from word 32 on
 //     28-29 (curved rays) V_t at the end / at the start of the geodesic -- written by extend
-//   Shade writes a wave's records as whole lines (they are contiguous in the next queue), extend reads the first 32
-//   bytes and answers into words 8-9.
+//   Shade writes a wave's records as whole lines (they are contiguous in the next queue), extend reads the first 32 bytes.
 //   shadow-wait queue entry = a parked frame waiting for connect's answers, 2 x float4 + nshadow terms:
 //     (bits(slot), sample id, RNG key, RNG counter) / (depth | tracker length << 8, tracker entry 0, term mask, flags)
 //   Lean entries (no refraction frame below them, scatterRays == 1) fill the queue from the front and are unwound by
@@ -195,6 +195,7 @@ struct Pool {
     float *trk;                          // [cap][ntrk]         RefractiveIndexTracker.indices 1 .. (entry 0 travels with the path)
     // queues
     float4 *q_rec[2];                    // extend queue (double buffered): one record per entry (R_*)
+    float2 *q_hit;                       // extend's answer per entry of the queue being traced: (status << 30 | primitive, t)
     uint8_t *q_cls;                      // class code of every entry of the queue being traced (extend)
     uint32_t *q_idx;                     // [NLIST][cap] entries of the queue being shaded, by list (bin_kernel)
     float4 *q_shpath[2];                 // paths waiting for their shadow rays, 2 x float4 per entry: lean ones from the front, the others from the back
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
                 if (dot(rel, rel) <= sc.bh.rs * sc.bh.rs) { status = HS_HORIZON; break; }   // :250-255
             }
         }
-        ((float2 *)rec)[R_HIT / 2] = make_float2(u2f((uint32_t)status << 30 | ((uint32_t)prim & 0x3FFFFFFFu)), t);
+        pl.q_hit[i] = make_float2(u2f((uint32_t)status << 30 | ((uint32_t)prim & 0x3FFFFFFFu)), t);
         pl.q_cls[i] = (uint8_t)classify(status, status == HS_HIT ? (uint32_t)sc.tri_class[prim] : 0u, f2u(qa.w) >> CTX_SHIFT);
         // shade reads the ray from the record: the origin of a hit (tracer.go:37 adds t to the CURRENT origin) and,
         // for a curved ray, the direction it ended with (the sky lookup of a miss, :260-263)
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Po
         },
         [&](const ExtTag &tag, const RayTrav &r) {
             const bool hit = r.best >= 0;
-            ((float2 *)rec_at(pl, cur, tag.entry))[R_HIT / 2] =
+            pl.q_hit[tag.entry] =
                 make_float2(u2f((uint32_t)(hit ? HS_HIT : HS_MISS) << 30 | ((uint32_t)r.best & 0x3FFFFFFFu)), hit ? r.best_t : 0.0f);
             pl.q_cls[tag.entry] = (uint8_t)classify(hit ? HS_HIT : HS_MISS, r.best_aux, tag.ctx);
         });
@@ -927,11 +928,11 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
             uint32_t e = pl.q_idx[(size_t)L_RET * pl.cap + i];
             if (e >= pl.it->n_ext) { err |= ERR_QUEUE; e = 0; }
             const float4 *rec = rec_at(pl, cur, e);
-            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+            const float4 r0 = rec[0], r1 = rec[1], r3 = rec[3];
             slot = f2u(r0.w) & (uint32_t)SLOT_MASK;
             const uint32_t ctx = f2u(r0.w) >> CTX_SHIFT;
             sid = f2u(r1.w);
-            const uint32_t status = f2u(r2.x) >> 30;
+            const uint32_t status = f2u(pl.q_hit[e].x) >> 30;
             depth = (int)(f2u(r3.x) & 0xFFu);
             uint32_t pneed = f2u(r3.y) >> 8;
             if (slot >= pl.cap) { err |= ERR_SLOT; slot = 0; }
@@ -1044,7 +1045,8 @@ __global__ __launch_bounds__(256) void shade_diff_kernel(Pool pl, DevScene sc, R
         if (slot >= pl.cap) { err |= ERR_SLOT; slot = 0; }
         sid = f2u(r1.w);
         Rng rng; rng.key = f2u(r2.z); rng.ctr = f2u(r2.w);
-        const uint32_t hitword = f2u(r2.x), packed = f2u(r3.x), fword = f2u(r3.y);
+        const float2 hq = pl.q_hit[e];
+        const uint32_t hitword = f2u(hq.x), packed = f2u(r3.x), fword = f2u(r3.y);
         int depth = (int)(packed & 0xFFu);
         if (depth >= pl.nframes) { err |= ERR_DEPTH; depth = 0; }
         uint32_t trk_len = (packed >> 8) & 0xFFu;
@@ -1061,7 +1063,7 @@ __global__ __launch_bounds__(256) void shade_diff_kernel(Pool pl, DevScene sc, R
         const V3 cur_o = mk(r0.x, r0.y, r0.z), cur_d = mk(r1.x, r1.y, r1.z);
         // ---- TraceRay :36-48, :93-113 (no disk), :49-91 (no glass), :116-118 (reflectivity < 0.1: HandleDiffuseMaterial)
         Hit h;
-        derive_hit(sc, cur_o, cur_d, r2.y, hprim, false, h, err);
+        derive_hit(sc, cur_o, cur_d, hq.y, hprim, false, h, err);
         const PtMaterial &m = sc.mats[h.mat];
         const float reflectivity = (m.ks[0] + m.ks[1] + m.ks[2]) / 3.0f;
         if ((m.flags & PTMI_MAT_GLASS) || ((m.flags & PTMI_MAT_ACCRETION) && sc.has_bh) || !(reflectivity < (float)0.1) ||
@@ -1109,7 +1111,7 @@ __global__ __launch_bounds__(256) void shade_diff_kernel(Pool pl, DevScene sc, R
         fw[F_LN] = ln.x; fw[F_LN + 1] = ln.y; fw[F_LN + 2] = ln.z;
         fw[F_RO] = cur_o.x; fw[F_RO + 1] = cur_o.y; fw[F_RO + 2] = cur_o.z;
         fw[F_RD] = cur_d.x; fw[F_RD + 1] = cur_d.y; fw[F_RD + 2] = cur_d.z;
-        fw[F_T] = r2.y; fw[F_PRIM] = i2f(h.prim);
+        fw[F_T] = hq.y; fw[F_PRIM] = i2f(h.prim);
         fw[F_DG] = 1.0f;
         fw[F_ALBEDO] = h.albedo.x; fw[F_ALBEDO + 1] = h.albedo.y; fw[F_ALBEDO + 2] = h.albedo.z;
         fw[F_PDIRECT] = pdirect.x; fw[F_PDIRECT + 1] = pdirect.y; fw[F_PDIRECT + 2] = pdirect.z;
@@ -1238,10 +1240,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const float4 r4 = (f2u(r3.y) & FL_SHORT) ? make_float4(0, 0, 0, 0) : rec[4];
             slot = f2u(qa.w) & (uint32_t)SLOT_MASK;
             sid = f2u(qb.w);
-            const uint32_t hitword = f2u(r2.x);
+            const float2 hq = pl.q_hit[e];
+            const uint32_t hitword = f2u(hq.x);
             hs = (int)(hitword >> 30);
             hprim = hs == HS_HIT ? (int)(hitword & 0x3FFFFFFFu) : -1;
-            ht = r2.y;
+            ht = hq.y;
             rng.key = f2u(r2.z); rng.ctr = f2u(r2.w);
             packed = f2u(r3.x);
             in_bounces = (int)(int8_t)((packed >> 16) & 0xFFu); in_bindex = (int)(packed >> 24);
@@ -1874,7 +1877,7 @@ static uint64_t pool_bytes_per_path(int bounces, int nlights, bool curved) {
     // buffered) + extend queue (records, double buffered; class byte; index lists) + shadow-wait queue (double
     // buffered) + free list
     return 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (32 + 1 + 16 * 2) * nshadow + 16 * (uint64_t)record_quads((int)nshadow, curved) * 2 +
-           1 + 4 * NLIST + 32 * 2 + 4;
+           8 + 1 + 4 * NLIST + 32 * 2 + 4;
 }
 
 static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes, bool curved) {
@@ -1887,7 +1890,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes, bool
     const int ntrk = tracker_words(bounces);
     const int rec_q = record_quads(nshadow, curved);
     const size_t c = cap;
-    struct Off { size_t fr, trk, qs0, qs1, ra, rb, occ, rec0, rec1, cls, idx, ss0, ss1, free_, cnt, it; } of[RenderState::MAX_LANES];
+    struct Off { size_t fr, trk, qs0, qs1, ra, rb, occ, rec0, rec1, hit, cls, idx, ss0, ss1, free_, cnt, it; } of[RenderState::MAX_LANES];
     size_t off = 0;
     for (int l = 0; l < lanes; ++l) {
         Off &o = of[l];
@@ -1896,7 +1899,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes, bool
         o.ra = carve(off, 16 * c * nshadow); o.rb = carve(off, 16 * c * nshadow); o.occ = carve(off, c * nshadow);
         o.ss0 = carve(off, 16 * c * nshadow); o.ss1 = carve(off, 16 * c * nshadow);
         o.rec0 = carve(off, 16 * c * rec_q); o.rec1 = carve(off, 16 * c * rec_q);
-        o.cls = carve(off, c + BIN_CHUNK); o.idx = carve(off, 4 * c * NLIST);
+        o.hit = carve(off, 8 * c); o.cls = carve(off, c + BIN_CHUNK); o.idx = carve(off, 4 * c * NLIST);
         o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * QC_COUNT * QC_STRIDE); o.it = carve(off, sizeof(IterArgs));
     }
     if (hipMalloc((void **)&rs->pool_mem, off) != hipSuccess) {
@@ -1915,7 +1918,7 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes, bool
         p.q_shp_sh[0] = (float4 *)(b + o.ss0); p.q_shp_sh[1] = (float4 *)(b + o.ss1);
         p.q_sray_occ = (uint8_t *)(b + o.occ);
         p.q_rec[0] = (float4 *)(b + o.rec0); p.q_rec[1] = (float4 *)(b + o.rec1);
-        p.q_cls = (uint8_t *)(b + o.cls); p.q_idx = (uint32_t *)(b + o.idx);
+        p.q_hit = (float2 *)(b + o.hit); p.q_cls = (uint8_t *)(b + o.cls); p.q_idx = (uint32_t *)(b + o.idx);
         p.q_shpath[0] = (float4 *)(b + o.qs0); p.q_shpath[1] = (float4 *)(b + o.qs1);
         p.q_sray_a = (float4 *)(b + o.ra); p.q_sray_b = (float4 *)(b + o.rb);
         p.q_free = (uint32_t *)(b + o.free_); p.qcnt = (unsigned long long *)(b + o.cnt);
