@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
 // LDS: the staged shadow rays ([word][thread], as in the general kernel), reused as the exchange area of the whole-line
 // stores once the rays are out: 16 words per thread at least, 20 with three shadow-ray kinds -- four workgroups per CU
 // and more where the general kernel has three.
-__global__ __launch_bounds__(256) void shade_diff_kernel(Pool pl, DevScene sc, RenderArgs ra, int cur, unsigned long long *counters) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void shade_diff_kernel(Pool pl, DevScene sc, RenderArgs ra, int cur, unsigned long long *counters) {
     const uint32_t n = (uint32_t)pl.qcnt[(size_t)(QC_LIST + L_DIFF) * QC_STRIDE];
     if (blockIdx.x * blockDim.x >= n) return;
     __shared__ float s_q[BK_N * 4];
