@@ -26,8 +26,13 @@ Prints ONE JSON line on rank 0.  Besides the contract's keys it carries
                         CheckIntersection single-threaded and on all cores of this job's CPU share, on a bounded
                         sample of the same batch; and the goroutine tile renderer (one worker thread per tile,
                         main.go:454-491, :832-899) on C1 with threadCount = 16 and = the CPU share.
-  render                samples/s of the wavefront integrator on C3 (BASELINE.json configs[2]); with N > 1 the frame is
-                        sharded by row blocks and reduced with RCCL through the C ABI (ptmi_render_sharded).
+  render, render_bounces4, render_c4, render_c5
+                        samples/s of the wavefront integrator on BASELINE.json configs[2] (C3; also with bounces = 4),
+                        configs[3] (C4: 10 M triangles, 4K, 64x64 tiles) and configs[4] (C5: black hole, 4K), at every N: with
+                        N > 1 the frame is sharded over the ranks and reduced with RCCL through the C ABI ("comm": "rccl";
+                        anything else, a failed rank or a hang makes the run exit non-zero after the line is printed).  At
+                        N = 1 each carries `roofline`: algorithmic bytes per kernel class (instrumented traversal kernels) /
+                        that class's time (the library's own per-kernel events).
 """
 from __future__ import annotations
 
@@ -420,28 +425,113 @@ def cpu_tile_renderer_baseline(args, dev):
     return out
 
 
-# ------------------------------------------------------------------------------------------------ render leg
-def render_leg(args, rank, world, dist, dev, torch):
-    """Secondary figure (not `value`): samples/s of the full wavefront integrator on BASELINE.json configs[2]
-    (C3: glass + emissive + gradient sky, 1920x1080, 256 spp, bounces 2).  With N > 1 the frame is sharded by
-    blocks of 8 rows over the ranks and summed onto rank 0 by ptmi_render_sharded (RCCL reduce behind the C ABI;
-    strong scaling)."""
-    from pathtrace_amd import scenes, sharded
+# ------------------------------------------------------------------------------------------------ render legs
+# The configurations BASELINE.json names for the integrator, each run at every N so that the N = 1 and N > 1 lines compare:
+RENDER_LEGS = {
+    "render": dict(scene="c3", width=1920, height=1080, spp=256, bounces=2, mode="rows",
+                   workload="C3: blob + glass spheres + emissive quad + mirror sphere, gradient sky + sun (BASELINE.json configs[2])"),
+    "render_bounces4": dict(scene="c3", width=1920, height=1080, spp=64, bounces=4, mode="rows",
+                            workload="C3 with bounces = 4 (SURVEY 8(d): 'bounces = 2, also report 4')"),
+    "render_c4": dict(scene="c4", width=3840, height=2160, spp=32, bounces=2, mode="tile",
+                      workload="C4: 10.4 M-triangle scene (blob over a height field, glass, mirror, emissive quad), 4K, 64x64 tiles dealt "
+                               "tile_id % N, frame reduced onto rank 0 (BASELINE.json configs[3]; 32 of its 1024 spp per timed frame)"),
+    "render_c5": dict(scene="c5", width=3840, height=2160, spp=2, bounces=2, mode="rows", max_steps=3000, step_size=1.0,
+                      workload="C5: black hole Rs = 100 + accretion disk, RK4 geodesic march maxSteps = 3000, stepSize = 1, 4K "
+                               "(BASELINE.json configs[4])"),
+}
+
+
+def _leg_scene(kind):
+    from pathtrace_amd import scenes
+    if kind == "c4":
+        return scenes.c4_scene()
+    if kind == "c5":
+        return scenes.blackhole_scene()
+    return scenes.bunny_scene(blob_level=6, glass=True, emissive=True)
+
+
+def render_roofline(r, run_one_gpu, leg, npix, nshadow):
+    """The render leg's roofline (N = 1): per kernel class, ALGORITHMIC bytes / that class's time.  Times: the library's
+    own per-kernel HIP events (ptmi_set_profiling: one wavefront loop, so the classes add up to the wall time).  Work:
+    the instrumented traversal kernels (ptmi_set_counting) on the same frame -- inner nodes popped (64 B each) and
+    triangles tested (48 B) by closest-hit and any-hit walks, query counts, queue entries shaded per kernel, frames
+    read back.  Per-unit constants: extend 64 N_inner + 48 N_tri + 41 per query (32 B ray, 8 B
+    answer, 1 B class); connect 64 N_inner + 48 N_tri + 33 per query; shade: 9 B per queue entry for the binning,
+    136 B per queue record read (72 for a fresh sample's one-sector record), 80 B triangle record per hit shaded, 64 B
+    per frame read or parked by the lean kernels (128 by the general kernel), 128 B per child record, 32 B per shadow
+    ray + 16 B per term, 20 B per finished sample (radiance + free list)."""
+    r.set_profiling(True)
+    run_one_gpu()
+    prof = r.profile()
+    r.set_profiling(False)
+    r.bvh.set_counting(True)
+    r.bvh.reset_counters()
+    run_one_gpu()
+    c = r.bvh.counters()
+    r.bvh.set_counting(False)
+    ci, ct = c.inner_visits - c.any_inner_visits, c.tri_tests - c.any_tri_tests
+    visits = c.shade_ret_visits + c.shade_diff_visits + c.shade_general_visits
+    hits_shaded = c.shade_diff_visits + c.shade_general_visits
+    entries = c.extend_entries                     # pending calls traced (== closest_queries unless a call marches in segments)
+    children = max(0, entries - c.samples)
+    shade_bytes = (9 * entries + 136 * children + 72 * c.samples + 80 * hits_shaded + 64 * c.frames_read +
+                   64 * c.shade_diff_visits + 128 * c.shade_general_visits + 128 * children + (32 + 16) * c.any_queries + 20 * c.samples)
+    rows = {"extend": (NODE_BYTES * ci + TRI_BYTES * ct + 41 * entries, prof["extend_ms"]),
+            "connect": (NODE_BYTES * c.any_inner_visits + TRI_BYTES * c.any_tri_tests + 33 * c.any_queries, prof["connect_ms"]),
+            "shade": (shade_bytes, prof["shade_ms"]),
+            "generate": (64 * c.samples, prof["generate_ms"]),
+            "accumulate": (12 * c.samples + 16 * npix, prof["accumulate_ms"])}
+    out = {"how": "per kernel class: algorithmic bytes (instrumented kernels of this run) / time (ptmi_set_profiling events, one wavefront loop)",
+           "hbm_peak": HBM_PEAK_GBS, "l1_gather_peak": L1_GATHER_PEAK_GBS}
+    total_b = total_ms = 0.0
+    for k, (bts, ms) in rows.items():
+        gbs = bts / max(ms, 1e-9) / 1e6
+        out[k] = {"algorithmic_bytes": int(bts), "ms": round(ms, 3), "GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                  "l1_gather_frac": round(gbs / L1_GATHER_PEAK_GBS, 4)}
+        total_b += bts
+        total_ms += ms
+    out["extend"].update(inner_per_query=round(ci / max(1, c.closest_queries), 3), tri_per_query=round(ct / max(1, c.closest_queries), 3),
+                         queries=int(c.closest_queries), entries=int(entries))
+    if leg.get("max_steps", 1) > 1:
+        out["extend"]["note"] = ("a marching call makes up to max_steps segment queries, most of them answered without a walk; the kernel is "
+                                 "bound by the RK4 step's arithmetic (four IEEE sqrt + divide pairs), not by bytes")
+    out["connect"].update(inner_per_query=round(c.any_inner_visits / max(1, c.any_queries), 2),
+                          tri_per_query=round(c.any_tri_tests / max(1, c.any_queries), 2))
+    out["shade"].update(visits=int(visits), ret_visits=int(c.shade_ret_visits), diff_visits=int(c.shade_diff_visits),
+                        general_visits=int(c.shade_general_visits), frames_read=int(c.frames_read))
+    total_ms += prof["prepare_ms"]
+    out["frame"] = {"algorithmic_bytes": int(total_b), "ms": round(total_ms, 3), "GBs": round(total_b / total_ms / 1e6, 1),
+                    "hbm_frac": round(total_b / total_ms / 1e6 / HBM_PEAK_GBS, 4), "iterations": int(prof["iterations"]),
+                    "launches": int(prof["launches"])}
+    return out
+
+
+def render_leg(name, args, rank, world, dist, dev, torch):
+    """Secondary figure (not `value`): samples/s of the full wavefront integrator on one of RENDER_LEGS.  With N > 1 the
+    frame is sharded (blocks of 8 rows, or 64x64 tiles, round-robin over the ranks), every rank renders its share in one
+    call and the frame is summed onto rank 0 through the C ABI's RCCL communicator (strong scaling)."""
+    from pathtrace_amd import sharded
     from pathtrace_amd.render import Renderer, make_params
-    sc = scenes.bunny_scene(blob_level=6, glass=True, emissive=True)
+    leg = dict(RENDER_LEGS[name])
+    if name == "render":
+        leg.update(width=args.render_width, height=args.render_height, spp=args.render_spp)
+    sc = _leg_scene(leg["scene"])
     r = Renderer(sc, device=dev.index)
-    W, H, spp = args.render_width, args.render_height, args.render_spp
-    p = make_params(W, H, bounces=2, scatter_rays=1, max_steps=1, step_size=1000.0, seed=1)
+    W, H, spp = leg["width"], leg["height"], leg["spp"]
+    p = make_params(W, H, bounces=leg["bounces"], scatter_rays=1, max_steps=leg.get("max_steps", 1), step_size=leg.get("step_size", 1000.0), seed=1)
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     cnt = torch.zeros((H, W), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    comm = None
-    if world > 1:
-        comm = sharded.make_comm(r, rank, world, dist, dev, rehearse=os.environ.get("PTMI_BENCH_REHEARSE") == "1")
+    rehearse = os.environ.get("PTMI_BENCH_REHEARSE") == "1"
+    comm = sharded.make_comm(r, rank, world, dist, dev, rehearse=rehearse) if world > 1 else None
+    render_tiles = sharded.make_device_render_tiles(r, p, sc.camera, stream)
 
     def run(spp_):
-        # every rank renders its row-interleaved share of the frame in one call, then one reduce onto rank 0
-        sharded.render_frame_sharded(r, comm, acc, cnt, p, sc.camera, spp_, row_block=8, root=0, stream=stream)
+        if leg["mode"] == "tile":       # the reference's tiles (main.go:454-491), a rank's share in one ptmi_render_tiles_dev call
+            sharded.render_sharded(None, acc, cnt, W, H, spp_, rank=rank, world=world, dst=0, mode="tile", tile=64,
+                                   render_tiles=render_tiles, comm=comm, stream=stream)
+        else:                           # every rank renders its row-interleaved share in one call, then one reduce onto rank 0
+            sharded.render_frame_sharded(r, comm, acc, cnt, p, sc.camera, spp_, row_block=8, root=0, stream=stream)
     run(spp)                                 # warm-up at full size: path pool and sample buffer allocation, RCCL channel set-up
     torch.cuda.synchronize()
     if dist is not None:
@@ -462,26 +552,34 @@ def render_leg(args, rank, world, dist, dev, torch):
         q[0] = mx[0]
     q = q.cpu().tolist()
     complete = bool((cnt == spp).all().item()) if rank == 0 else True
+    share = "blocks of 8 rows" if leg["mode"] == "rows" else "64x64 tiles"
     if world == 1:
-        how = "single GPU"
+        how, kind = f"single GPU ({share} in one call)", "single"
     else:
-        how = f"blocks of 8 rows round-robin over {world} ranks, one render call per rank + "
+        how = f"{share} round-robin over {world} ranks, one render call per rank + "
         if comm.kind == "rccl":
-            how += "RCCL ncclReduce behind the C ABI (ptmi_render_sharded)"
-        elif os.environ.get("PTMI_BENCH_REHEARSE") == "1":
+            how += "RCCL ncclReduce behind the C ABI (ptmi_render_sharded / ptmi_reduce_frame)"
+            kind = "rccl"
+        elif rehearse:
             how += "host-staged gloo reduce (rehearsal)"
+            kind = "rehearsal"
         else:
             how += f"torch.distributed reduce (the C ABI's communicator was not available: {comm.note})"
+            kind = "fallback"
+    out = {"metric": "samples/s, full multi-bounce integrator", "value": round(W * H * spp / q[0] / 1e6, 2),
+           "unit": "Msamples/s", "seconds": round(q[0], 4), "comm": kind,
+           "config": {"workload": leg["workload"], "width": W, "height": H, "spp": spp, "bounces": leg["bounces"],
+                      "max_steps": leg.get("max_steps", 1), "triangles": int(sc.tris.shape[0]), "sharding": how},
+           "closest_hit_Mqueries_per_s": round(q[1] / q[0] / 1e6, 1), "any_hit_Mqueries_per_s": round(q[2] / q[0] / 1e6, 1),
+           "diffuse_events_M_per_s": round(q[3] / q[0] / 1e6, 1), "frame_complete": complete}
+    if world == 1 and not args.no_render_roofline:
+        out["roofline"] = render_roofline(r, lambda: (run(spp), torch.cuda.synchronize()), leg, W * H, int(sc.lights.shape[0]) + 2)
     if comm is not None:
         comm.close()
-    return {"metric": "samples/s, full multi-bounce integrator", "value": round(W * H * spp / q[0] / 1e6, 2),
-            "unit": "Msamples/s", "seconds": round(q[0], 4),
-            "config": {"workload": "C3: blob + glass spheres + emissive quad + mirror sphere, gradient sky + sun "
-                                   "(BASELINE.json configs[2])", "width": W, "height": H, "spp": spp, "bounces": 2,
-                       "triangles": int(sc.tris.shape[0]),
-                       "sharding": how},
-            "closest_hit_Mqueries_per_s": round(q[1] / q[0] / 1e6, 1), "any_hit_Mqueries_per_s": round(q[2] / q[0] / 1e6, 1),
-            "diffuse_events_M_per_s": round(q[3] / q[0] / 1e6, 1), "frame_complete": complete}
+    r.ctx.close()
+    del r, acc, cnt
+    torch.cuda.empty_cache()
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -502,7 +600,9 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU time budget of the closest-hit baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--render-timeout", type=float, default=240.0, help="N > 1: seconds after which a stuck render leg is given up")
+    ap.add_argument("--render-timeout", type=float, default=420.0, help="N > 1: seconds after which stuck render legs are given up")
+    ap.add_argument("--render-legs", default="render,render_bounces4,render_c4,render_c5", help="comma-separated subset of the render legs")
+    ap.add_argument("--no-render-roofline", action="store_true", help="skip the profiled + counted frames of the render legs (N = 1)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -633,44 +733,63 @@ def main():
         del wl2
         torch.cuda.empty_cache()
 
-    # The primary figure is complete here.  With N > 1 the render leg enters collectives (communicator set-up, the frame
+    # The primary figure is complete here.  With N > 1 the render legs enter collectives (communicator set-up, the frame
     # reduce): if a rank fails or hangs there, the others would wait for ever and the whole line would be lost, so a
-    # watchdog per rank ends the process after --render-timeout seconds; rank 0 prints the line without the render leg.
-    state = {"printed": False}
+    # watchdog per rank ends the process after --render-timeout seconds; rank 0 prints the line with what it has.  Such
+    # a run -- and one in which a rank raised, or whose reduce did not go through the C ABI's RCCL communicator although
+    # it should have -- exits NON-ZERO after the line is out: it must not pass for a measurement of the RCCL path.
+    state = {"printed": False, "failed": ""}
     watchdog = None
     if world > 1:
         import threading
 
         def give_up():
             if rank == 0 and not state["printed"]:
-                out["render"] = {"error": f"the render leg did not finish within {args.render_timeout:.0f} s (a rank failed or a "
-                                          "collective hung); the primary figure above is unaffected"}
+                out["render_error"] = (f"the render legs did not finish within {args.render_timeout:.0f} s (a rank failed or a "
+                                       "collective hung); the primary figure above is unaffected")
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)
         watchdog = threading.Timer(args.render_timeout, give_up)
         watchdog.daemon = True
         watchdog.start()
-    render = None
-    if not args.no_render:
+    legs = [] if args.no_render else [l for l in args.render_legs.split(",") if l]
+    for name in legs:
+        if name not in RENDER_LEGS:
+            raise SystemExit(f"unknown render leg {name!r}; known: {', '.join(RENDER_LEGS)}")
         try:
-            render = render_leg(args, rank, world, dist, dev, torch)
+            leg = render_leg(name, args, rank, world, dist, dev, torch)
         except Exception as e:               # noqa: BLE001 -- reported in the line, the primary figure stands
             if world == 1:
                 raise
-            render = {"error": f"rank {rank}: {type(e).__name__}: {e}"}
+            leg = {"error": f"rank {rank}: {type(e).__name__}: {e}"}
+            state["failed"] = leg["error"]
+        if leg.get("comm") == "fallback":
+            state["failed"] = state["failed"] or f"{name}: the frame reduce fell back to torch.distributed"
+        if rank == 0:
+            out[name] = leg
+        log(f"[rank {rank}] {name}: {leg.get('value', leg.get('error'))} {leg.get('unit', '')}")
     if rank == 0:
-        if render is not None:
-            out["render"] = render
         if world == 1 and not args.no_cpu_baseline:
             tb = cpu_tile_renderer_baseline(args, dev)
             out["cpu_baseline"]["tile_renderer"] = tb
         print(json.dumps(out), flush=True)
         state["printed"] = True
+    failed = state["failed"]
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        # every rank learns whether any rank failed, so that all exit with the same code
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=dev)
+        try:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = failed or ("another rank failed in a render leg" if int(flag.item()) else "")
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:               # noqa: BLE001
+            failed = failed or f"{type(e).__name__}: {e}"
     if watchdog is not None:
         watchdog.cancel()
+    if failed:
+        log(f"[rank {rank}] FAILED: {failed}")
+        sys.exit(4)
 
 
 if __name__ == "__main__":

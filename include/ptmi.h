@@ -134,7 +134,8 @@ int ptmi_any_hit_dev(ptmi_ctx *ctx, const float *o_xyz, const float *d_xyz, cons
 
 /* Work counters.  The reference only counts diffuse shading events (raysTraced, tracer.go:12,666);
  * the traversal counters here define the algorithmic bytes of the roofline.
- * Counting is off by default (it selects instrumented kernel variants). */
+ * Counting is off by default (it selects instrumented kernel variants: of the batch kernels and of the
+ * integrator's extend / connect). */
 typedef struct {
     uint64_t closest_queries, any_queries;
     uint64_t inner_visits;     /* inner nodes popped  (64 B each)  */
@@ -142,6 +143,12 @@ typedef struct {
     uint64_t leaf_visits;
     uint64_t diffuse_events;   /* == raysTraced (tracer.go:666)    */
     uint64_t samples;          /* primary samples completed        */
+    /* the any-hit walks' share of inner_visits / tri_tests (the closest-hit share is the rest) */
+    uint64_t any_inner_visits, any_tri_tests;
+    /* integrator bookkeeping for the render leg's roofline (always counted): queue entries shaded by the kernel for
+     * returning calls / fresh diffuse hits / everything else, and parked frames read back */
+    uint64_t shade_ret_visits, shade_diff_visits, shade_general_visits, frames_read;
+    uint64_t extend_entries;   /* pending TraceRay calls traced (a marching call makes many closest-hit queries) */
 } PtCounters;
 int ptmi_set_counting(ptmi_ctx *ctx, int enabled);
 int ptmi_reset_counters(ptmi_ctx *ctx);

@@ -33,7 +33,9 @@ class PtBvhStats(C.Structure):
 class PtCounters(C.Structure):
     _fields_ = [("closest_queries", C.c_uint64), ("any_queries", C.c_uint64), ("inner_visits", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("leaf_visits", C.c_uint64), ("diffuse_events", C.c_uint64),
-                ("samples", C.c_uint64)]
+                ("samples", C.c_uint64), ("any_inner_visits", C.c_uint64), ("any_tri_tests", C.c_uint64),
+                ("shade_ret_visits", C.c_uint64), ("shade_diff_visits", C.c_uint64), ("shade_general_visits", C.c_uint64),
+                ("frames_read", C.c_uint64), ("extend_entries", C.c_uint64)]
 
 
 class PtRenderProfile(C.Structure):

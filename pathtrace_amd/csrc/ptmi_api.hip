@@ -53,6 +53,10 @@ __device__ __forceinline__ void flush_counters(const TravCounters &c, unsigned l
         atomicAdd(&counters[CNT_TRI], (unsigned long long)vt);
         atomicAdd(&counters[CNT_LEAF], (unsigned long long)vl);
         atomicAdd(&counters[which_query], (unsigned long long)va);
+        if (which_query == CNT_ANY) {
+            atomicAdd(&counters[CNT_INNER_ANY], (unsigned long long)vi);
+            atomicAdd(&counters[CNT_TRI_ANY], (unsigned long long)vt);
+        }
     }
 }
 
@@ -745,5 +749,8 @@ extern "C" int ptmi_counters(ptmi_ctx *ctx, PtCounters *out) {
     out->closest_queries = h[CNT_CLOSEST]; out->any_queries = h[CNT_ANY]; out->inner_visits = h[CNT_INNER];
     out->tri_tests = h[CNT_TRI]; out->leaf_visits = h[CNT_LEAF]; out->diffuse_events = h[CNT_DIFFUSE];
     out->samples = h[CNT_SAMPLES];
+    out->any_inner_visits = h[CNT_INNER_ANY]; out->any_tri_tests = h[CNT_TRI_ANY];
+    out->shade_ret_visits = h[CNT_VISIT_RET]; out->shade_diff_visits = h[CNT_VISIT_DIFF]; out->shade_general_visits = h[CNT_VISIT_GEN];
+    out->frames_read = h[CNT_FRAMES]; out->extend_entries = h[CNT_ENTRIES];
     return PTMI_OK;
 }

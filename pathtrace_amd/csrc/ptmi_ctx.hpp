@@ -14,6 +14,10 @@
 enum {
     CNT_CLOSEST = 0, CNT_ANY = 1, CNT_INNER = 2, CNT_TRI = 3, CNT_LEAF = 4, CNT_DIFFUSE = 5, CNT_SAMPLES = 6,
     CNT_ERROR = 8,         // bit set of integrator self-check failures (ptmi_render.hip: ERR_*), must stay 0
+    CNT_INNER_ANY = 9, CNT_TRI_ANY = 10,                         // the any-hit walks' share of CNT_INNER / CNT_TRI
+    CNT_VISIT_RET = 11, CNT_VISIT_DIFF = 12, CNT_VISIT_GEN = 13, // queue entries shaded, by kernel
+    CNT_FRAMES = 14,                                             // parked frames read back
+    CNT_ENTRIES = 15,                                            // extend-queue entries traced
     CNT_WORDS = 16,        // one shard = 16 words = one 128-byte line
     // Atomics on one line are served one at a time, ~12 ns each, whichever word they address (measured,
     // tools/ubench_atomic.hip): 20 000 waves adding to one counter block take 0.25 ms for that alone.  The block is

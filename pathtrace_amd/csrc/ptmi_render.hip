@@ -282,6 +282,7 @@ __global__ void iter_prep_kernel(Pool pl, int cur, unsigned long long total, uns
     if (n_ext + ng > pl.cap) ng = pl.cap - n_ext;
     a.gen_n = (uint32_t)ng; a.gen_base = (uint32_t)n_ext; a.first_sample = next;
     a.n_ext = (uint32_t)(n_ext + ng); a.n_shp = (uint32_t)n_shp; a.n_sha = (uint32_t)n_sha;
+    if (n_ext + ng) atomicAdd(&counters[CNT_ENTRIES], n_ext + ng);
     a.pad[0] = a.pad[1] = 0;
     *pl.it = a;
     qc(QC_NEXT) = next + ng;
@@ -414,6 +415,23 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, i
     }
 }
 
+// Work counters of the integrator's walks (ptmi_set_counting: the COUNT = true instantiations): inner nodes popped,
+// triangles tested, leaves visited -- what the render leg's roofline prices (64 / 48 bytes each).  The query counts
+// (CNT_CLOSEST / CNT_ANY) are kept by every instantiation.
+template <bool COUNT, bool ANY>
+__device__ __forceinline__ void flush_walk_counters(const TravCounters &c, unsigned long long *counters) {
+    if (!COUNT) return;
+    uint32_t vi = c.inner, vt = c.tri, vl = c.leaf;
+    for (int off = 32; off > 0; off >>= 1) { vi += __shfl_xor(vi, off); vt += __shfl_xor(vt, off); vl += __shfl_xor(vl, off); }
+    if ((threadIdx.x & 63) == 0) {
+        counters = counter_shard(counters);
+        atomicAdd(&counters[CNT_INNER], (unsigned long long)vi);
+        atomicAdd(&counters[CNT_TRI], (unsigned long long)vt);
+        atomicAdd(&counters[CNT_LEAF], (unsigned long long)vl);
+        if (ANY) { atomicAdd(&counters[CNT_INNER_ANY], (unsigned long long)vi); atomicAdd(&counters[CNT_TRI_ANY], (unsigned long long)vt); }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ extend
 // The march loop of TraceRay (tracer.go:33-35, 226-256): closest hit on the segment [0, stepSize];
 // on a miss advance (straight) or RK4-step the geodesic (curved) and test the horizon.
@@ -421,13 +439,14 @@ __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, i
 // it writes the ray back into its entry only when shade needs the moved one (a hit after marching, a curved ray).
 // Runs on a fixed grid and loops over the queue; leaves at once when the launch is large enough for the vote-scheduled
 // kernel to take it (vote_from).
-template <int STACK, bool CURVED>
+template <int STACK, bool CURVED, bool COUNT>
 __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl, DevScene sc, RenderArgs ra, int cur,
                                                              uint32_t vote_from, unsigned long long *counters) {
     __shared__ uint32_t smem[STACK * WAVE];
     const uint32_t n = pl.it->n_ext;
     if (n >= vote_from) return;
     uint32_t nq = 0;
+    TravCounters tc;
     for (uint32_t base = blockIdx.x * WAVE; base < n; base += gridDim.x * WAVE) {
         const uint32_t i = base + threadIdx.x;
         if (i >= n) continue;
@@ -441,12 +460,11 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
         int status = HS_MISS, prim = -1;
         float t = 0.0f;
         bool moved = false;
-        TravCounters tc;
         for (int step = 0; step < ra.p.max_steps; ++step) {
             ++nq;
             // a geodesic spends most of its 3 000 segments far from any geometry: those queries are misses without a walk
             if (CURVED && segment_outside_tree(bvh, o.x, o.y, o.z, d.x, d.y, d.z, ra.p.step_size)) { prim = -1; t = 0.0f; }
-            else closest_hit<WAVE, false>(bvh, smem + threadIdx.x, o.x, o.y, o.z, d.x, d.y, d.z, ra.p.step_size, prim, t, tc);
+            else closest_hit<WAVE, COUNT>(bvh, smem + threadIdx.x, o.x, o.y, o.z, d.x, d.y, d.z, ra.p.step_size, prim, t, tc);
             if (prim >= 0) { status = HS_HIT; break; }
             moved = true;
             if (!CURVED) {
@@ -473,6 +491,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
     }
     for (int off = 32; off > 0; off >>= 1) nq += __shfl_xor(nq, off);
     if ((threadIdx.x & 63) == 0 && nq) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)nq);
+    flush_walk_counters<COUNT, false>(tc, counters);
 }
 
 // extend for straight rays with one segment per call (max_steps == 1, no black hole): persistent waves walking
@@ -486,7 +505,7 @@ __device__ __forceinline__ uint32_t vote_chunk(uint64_t n, uint32_t chunk_max) {
     return (uint32_t)min((uint64_t)chunk_max, max((uint64_t)WAVE, fair));
 }
 struct ExtTag { uint32_t entry, ctx; };
-template <int STACK>
+template <int STACK, bool COUNT>
 __global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Pool pl, RenderArgs ra, int cur, uint32_t vote_from, unsigned long long *counters, int refill_min,
                                                                   int tri_bias, uint32_t chunk_max) {
     __shared__ uint32_t smem[STACK * WAVE];
@@ -494,7 +513,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Po
     if (n < vote_from || (uint64_t)blockIdx.x * WAVE >= n) return;          // the one-shot kernel takes small launches
     const float step = ra.p.step_size;
     TravCounters cnt;
-    vote_walk<WAVE, false, false, ExtTag, true>(
+    vote_walk<WAVE, false, COUNT, ExtTag, true>(
         bvh, smem + threadIdx.x, n, pl.qcnt + (size_t)QC_CURSOR_EXT * QC_STRIDE, refill_min, tri_bias, vote_chunk(n, chunk_max), cnt,
         [&](uint64_t idx, NextRay &nx, ExtTag &tag) {
             const float4 *rec = rec_at(pl, cur, idx);
@@ -509,6 +528,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Po
             pl.q_cls[tag.entry] = (uint8_t)classify(hit ? HS_HIT : HS_MISS, r.best_aux, tag.ctx);
         });
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counter_shard(counters)[CNT_CLOSEST], (unsigned long long)n);
+    flush_walk_counters<COUNT, false>(cnt, counters);
 }
 
 // ------------------------------------------------------------------------------------------ bin
@@ -588,26 +608,27 @@ __device__ __forceinline__ uint64_t sray_total(const ShadowCounts &sn) {
 }
 
 // One-shot waves on a fixed grid, for launches too small for the vote-scheduled kernel.
-template <int STACK>
+template <int STACK, bool COUNT>
 __global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool pl, int cur, uint32_t vote_from, unsigned long long *counters) {
     __shared__ uint32_t smem[STACK * WAVE];
     const ShadowCounts sn = pl.it->sray;
     const uint64_t n = sray_total(sn);
     if (n >= vote_from) return;
+    TravCounters tc;
     for (uint32_t base = blockIdx.x * WAVE; base < n; base += gridDim.x * WAVE) {
         const uint32_t j = base + threadIdx.x;
         if (j >= n) continue;
         const size_t e = sray_entry(pl, sn, j);
         const float4 a = pl.q_sray_a[e], bb = pl.q_sray_b[e];
-        TravCounters tc;
-        pl.q_sray_occ[e] = any_hit<WAVE, false>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc) ? 1 : 0;
+        pl.q_sray_occ[e] = any_hit<WAVE, COUNT>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc) ? 1 : 0;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
+    flush_walk_counters<COUNT, true>(tc, counters);
 }
 
 // connect: persistent waves walking vote-scheduled single steps (vote_walk, trav_device.hpp), shadow rays dealt in
 // chunks from one cursor over the buckets laid end to end (a chunk is nearly always of one kind).
-template <int STACK>
+template <int STACK, bool COUNT>
 __global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, Pool pl, int cur, uint32_t vote_from, unsigned long long *counters,
                                                                    int refill_min, int tri_bias, uint32_t chunk_max) {
     __shared__ uint32_t smem[STACK * WAVE];
@@ -615,7 +636,7 @@ __global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, P
     const uint64_t n = sray_total(sn);
     if (n < vote_from || (uint64_t)blockIdx.x * WAVE >= n) return;
     TravCounters cnt;
-    vote_walk<WAVE, true, false, uint32_t>(
+    vote_walk<WAVE, true, COUNT, uint32_t>(
         bvh, smem + threadIdx.x, n, pl.qcnt + (size_t)QC_CURSOR * QC_STRIDE, refill_min, tri_bias, vote_chunk(n, chunk_max), cnt,
         [&](uint64_t idx, NextRay &nx, uint32_t &pos) {
             const size_t e = sray_entry(pl, sn, (uint32_t)idx);
@@ -624,6 +645,7 @@ __global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, P
         },
         [&](uint32_t pos, const RayTrav &r) { pl.q_sray_occ[pos] = r.best ? 1 : 0; });   // the answer goes beside the ray (one byte)
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
+    flush_walk_counters<COUNT, true>(cnt, counters);
 }
 
 // ------------------------------------------------------------------------------------------ shade
@@ -818,7 +840,7 @@ struct TailPos {              // where its entries go
 };
 // sq: LDS words [BK_N][4] (as float bit patterns: one access type per LDS word); the workgroup's waves must all call.
 __device__ __forceinline__ TailPos tail_reserve(const Pool &pl, int cur, float *sq, const TailOut &o, uint32_t diffuse_events,
-                                                unsigned long long *counters) {
+                                                unsigned long long *counters, int visit_counter, bool visited, uint32_t frames_read) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const bool shp_lean = o.want_shadow && !o.anc, shp_anc = o.want_shadow && o.anc;
@@ -835,7 +857,8 @@ __device__ __forceinline__ TailPos tail_reserve(const Pool &pl, int cur, float *
     unsigned long long m_ray[NSB - 1];
 #pragma unroll
     for (int b = 0; b < NSB - 1; ++b) m_ray[b] = __ballot((o.need_out >> b) & 1u);
-    for (int off = 32; off > 0; off >>= 1) diffuse_events += __shfl_xor(diffuse_events, off);
+    for (int off = 32; off > 0; off >>= 1) { diffuse_events += __shfl_xor(diffuse_events, off); frames_read += __shfl_xor(frames_read, off); }
+    const uint32_t nvisited = (uint32_t)__popcll(__ballot(visited));
 #define SQ(q, w) f2u(sq[(q) * 4 + (w)])
 #define SQ_SET(q, w, v) (sq[(q) * 4 + (w)] = u2f(v))
     if (lane == 63) {
@@ -857,7 +880,12 @@ __device__ __forceinline__ TailPos tail_reserve(const Pool &pl, int cur, float *
         SQ_SET(q, 0, base); SQ_SET(q, 1, base + c0); SQ_SET(q, 2, base + c0 + c1); SQ_SET(q, 3, base + c0 + c1 + c2);
         if (q == BK_FREE && total) atomicAdd(&counter_shard(counters)[CNT_SAMPLES], (unsigned long long)total);
     }
-    if (lane == 0 && diffuse_events) atomicAdd(&counter_shard(counters)[CNT_DIFFUSE], (unsigned long long)diffuse_events);
+    if (lane == 0) {
+        unsigned long long *cs = counter_shard(counters);
+        if (diffuse_events) atomicAdd(&cs[CNT_DIFFUSE], (unsigned long long)diffuse_events);
+        if (nvisited) atomicAdd(&cs[visit_counter], (unsigned long long)nvisited);
+        if (frames_read) atomicAdd(&cs[CNT_FRAMES], (unsigned long long)frames_read);
+    }
     lds_barrier();
     TailPos p;
     p.ext = SQ(BK_EXT, wv) + (uint32_t)__popcll(m_ext & lt);
@@ -918,7 +946,7 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool pending = i < na, parked = i >= na_pad && i - na_pad < nb;
     TailOut to;
-    uint32_t diffuse_events = 0;
+    uint32_t diffuse_events = 0, frames_read = 0;
     if (pending || parked) {
         uint32_t err = 0, sid = 0, slot = 0;
         int depth = 0;
@@ -952,6 +980,7 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
             const float4 *terms = pl.q_shp_sh[cur] + k * (size_t)pl.nshadow;
             const V3 direct = sum_free_terms(pl, pneed, err, [&](int t) { return terms[t]; });
             // the parked frame: HandleDiffuseMaterial's final sum with no GI rays (bounces <= 0), then TraceRay's (:218-223)
+            frames_read++;
             const float4 *f = frame_at(depth);
             const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
             const uint32_t bb = f2u(f0.x), sp = f2u(f0.y);
@@ -971,6 +1000,7 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
         // unwind: hand `ret` to the caller frame, and with it the caller's direct lighting this call carried
         while (depth > 0 && !err) {
             depth--;
+            frames_read++;
             const float4 *f = frame_at(depth);
             const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
             const uint32_t bb = f2u(f0.x), sp = f2u(f0.y);
@@ -1004,7 +1034,7 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
         o[0] = ret.x; o[1] = ret.y; o[2] = ret.z;
         to.finished = true; to.slot = slot;
     }
-    const TailPos tp = tail_reserve(pl, cur, s_q, to, diffuse_events, counters);
+    const TailPos tp = tail_reserve(pl, cur, s_q, to, diffuse_events, counters, CNT_VISIT_RET, pending || parked, frames_read);
     if (to.finished) pl.q_free[tp.fin] = to.slot;
 }
 
@@ -1123,7 +1153,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             to.want_extend = to.want_shadow = false; to.need_out = 0; to.finished = true; frame_dst = nullptr;
         }
     }
-    const TailPos tp = tail_reserve(pl, cur, s_q, to, 0u, counters);
+    const TailPos tp = tail_reserve(pl, cur, s_q, to, 0u, counters, CNT_VISIT_DIFF, i < n, 0u);
     // shadow rays out of the staging area; their terms into the child's record (first rec_inline of them: registers,
     // stored with the record's lines) or beside the shadow-wait entry
     float4 *rec_dst = to.want_extend ? rec_at(pl, cur ^ 1, tp.ext) : nullptr;
@@ -1214,7 +1244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     bool want_extend = false, want_shadow = false, finished = false, anc_out = false;
     uint32_t n_sray = 0;                       // shadow rays this path wants to enqueue
     uint32_t need_out = 0;                     // their kinds (bit k = shadow ray kind k)
-    uint32_t diffuse_events = 0;
+    uint32_t diffuse_events = 0, frames_read = 0;
     V3 out_o = mk(0, 0, 0), out_d = mk(0, 0, 0);   // the ray of a path that wants an extend (goes into its queue entry)
     uint32_t out_sid = 0, out_key = 0, out_ctr = 0, out_pack = 0, out_flags = 0, out_ctx = 0, out_depth_trk = 0;
     float out_energy = 0.0f, out_trk0 = 1.0f;
@@ -1287,6 +1317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #define FW(field) s_fw[(field) * 256 + tid]
 #endif
         auto load_frame = [&](int dep) {
+            frames_read++;
             const float4 *f = frames + (size_t)dep * 8;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const float4 v = f[k]; FW(4 * k) = v.x; FW(4 * k + 1) = v.y; FW(4 * k + 2) = v.z; FW(4 * k + 3) = v.w; }
@@ -1582,7 +1613,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ float s_q[BK_N * 4];
     TailOut to;
     to.want_extend = want_extend; to.want_shadow = want_shadow; to.finished = finished; to.anc = anc_out; to.need_out = need_out; to.slot = slot;
-    const TailPos tp = tail_reserve(pl, cur, s_q, to, diffuse_events, counters);
+    const TailPos tp = tail_reserve(pl, cur, s_q, to, diffuse_events, counters, CNT_VISIT_GEN, live, frames_read);
     {
         // The child's record is put together in the frame area (this thread's column: the frame store above has read
         // it, and LDS accesses of one wave complete in order) and stored as a whole line, like the frames.
@@ -1976,7 +2007,7 @@ static void prof_collect(ptmi_ctx *ctx) {
 
 // One iteration of the wavefront loop on queue buffer `cur`, enqueued without knowing its sizes (IterArgs); the grids
 // cover the most paths the call can have in flight (the pool, or all of the call's samples if those are fewer).
-template <int STACK>
+template <int STACK, bool COUNT>
 static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, const BinMap &bm, uint64_t lane_total,
                                int cur, hipStream_t s) {
     const uint64_t most = std::min<uint64_t>(pl.cap, lane_total);
@@ -1988,40 +2019,40 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
     // extend
     uint32_t vote_from = VOTE_NEVER;
     if (!sc.has_bh && ra.p.max_steps == 1 && ctx->extend_vote) {
-        const int per_cu = std::min(ctx->waves_per_cu((const void *)render_extend_vote_kernel<STACK>, WAVE), ctx->persist_waves_per_cu);
+        const int per_cu = std::min(ctx->waves_per_cu((const void *)render_extend_vote_kernel<STACK, COUNT>, WAVE), ctx->persist_waves_per_cu);
         vote_from = vote_from_for(ctx, per_cu);
         const unsigned pgrid = (unsigned)std::min<uint64_t>(cap_waves, (uint64_t)ctx->num_cus * per_cu);
         if (most >= vote_from)          // a call this small never has a queue that long: one launch less per iteration
             timed(ctx, PROF_EXTEND, s, [&] {
-                hipLaunchKernelGGL((render_extend_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, cur, vote_from,
+                hipLaunchKernelGGL((render_extend_vote_kernel<STACK, COUNT>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, ra, cur, vote_from,
                                    ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk); });
     }
     if (vote_from > 0) {
         const unsigned grid = (unsigned)std::min<uint64_t>(cap_waves, ((uint64_t)vote_from + WAVE - 1) / WAVE);
         timed(ctx, PROF_EXTEND, s, [&] {
             if (sc.has_bh)
-                hipLaunchKernelGGL((render_extend_kernel<STACK, true>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, sc, ra, cur,
+                hipLaunchKernelGGL((render_extend_kernel<STACK, true, COUNT>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, sc, ra, cur,
                                    vote_from, ctx->d_counters);
             else
-                hipLaunchKernelGGL((render_extend_kernel<STACK, false>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, sc, ra, cur,
+                hipLaunchKernelGGL((render_extend_kernel<STACK, false, COUNT>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, sc, ra, cur,
                                    vote_from, ctx->d_counters); });
     }
     // connect
     const uint64_t ray_waves = (most * (uint64_t)pl.nshadow + WAVE - 1) / WAVE;
     vote_from = VOTE_NEVER;
     if (ctx->connect_vote) {
-        const int per_cu = std::min(ctx->waves_per_cu((const void *)render_connect_vote_kernel<STACK>, WAVE), ctx->persist_waves_per_cu);
+        const int per_cu = std::min(ctx->waves_per_cu((const void *)render_connect_vote_kernel<STACK, COUNT>, WAVE), ctx->persist_waves_per_cu);
         vote_from = vote_from_for(ctx, per_cu);
         const unsigned pgrid = (unsigned)std::min<uint64_t>(ray_waves, (uint64_t)ctx->num_cus * per_cu);
         if (most * (uint64_t)pl.nshadow >= vote_from)
             timed(ctx, PROF_CONNECT, s, [&] {
-                hipLaunchKernelGGL((render_connect_vote_kernel<STACK>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, cur, vote_from,
+                hipLaunchKernelGGL((render_connect_vote_kernel<STACK, COUNT>), dim3(pgrid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, cur, vote_from,
                                    ctx->d_counters, ctx->render_vote_refill_min, ctx->vote_tri_bias, (uint32_t)ctx->render_vote_chunk); });
     }
     if (vote_from > 0) {
         const unsigned grid = (unsigned)std::min<uint64_t>(ray_waves, ((uint64_t)vote_from + WAVE - 1) / WAVE);
         timed(ctx, PROF_CONNECT, s, [&] {
-            hipLaunchKernelGGL((render_connect_kernel<STACK>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, cur, vote_from, ctx->d_counters); });
+            hipLaunchKernelGGL((render_connect_kernel<STACK, COUNT>), dim3(grid), dim3(WAVE), 0, s, ctx->dev_bvh(), pl, cur, vote_from, ctx->d_counters); });
     }
     // shade: the class bytes extend wrote become index lists, then one kernel per class (all three count as shade time)
     const size_t ray_lds = (size_t)(SRW * pl.nshadow - 1) * 256 * sizeof(float);
@@ -2038,13 +2069,13 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
 static int enqueue_iteration(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, const BinMap &bm, uint64_t lane_total,
                              int cur, hipStream_t s) {
     const int dep = ctx->stack_entries();
-    if (dep <= 16) return enqueue_iteration_t<16>(ctx, pl, sc, ra, bm, lane_total, cur, s);
-    if (dep <= 20) return enqueue_iteration_t<20>(ctx, pl, sc, ra, bm, lane_total, cur, s);
-    if (dep <= 24) return enqueue_iteration_t<24>(ctx, pl, sc, ra, bm, lane_total, cur, s);
-    if (dep <= 28) return enqueue_iteration_t<28>(ctx, pl, sc, ra, bm, lane_total, cur, s);
-    if (dep <= 32) return enqueue_iteration_t<32>(ctx, pl, sc, ra, bm, lane_total, cur, s);
-    if (dep <= 48) return enqueue_iteration_t<48>(ctx, pl, sc, ra, bm, lane_total, cur, s);
-    return enqueue_iteration_t<64>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    if (dep <= 16) return ctx->counting ? enqueue_iteration_t<16, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<16, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    if (dep <= 20) return ctx->counting ? enqueue_iteration_t<20, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<20, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    if (dep <= 24) return ctx->counting ? enqueue_iteration_t<24, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<24, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    if (dep <= 28) return ctx->counting ? enqueue_iteration_t<28, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<28, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    if (dep <= 32) return ctx->counting ? enqueue_iteration_t<32, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<32, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    if (dep <= 48) return ctx->counting ? enqueue_iteration_t<48, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<48, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    return ctx->counting ? enqueue_iteration_t<64, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<64, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
 }
 
 // Renders samples [spp_begin, spp_begin+spp_count) of the rectangle into d_out chunks and accumulates them

@@ -30,7 +30,7 @@ static void host_checks(void) {
     CHECK(sizeof(PtBlackHole) == 32);
     CHECK(sizeof(PtCamera) == 52);
     CHECK(sizeof(PtParams) == 32);
-    CHECK(sizeof(PtCounters) == 56);
+    CHECK(sizeof(PtCounters) == 112);
     CHECK(strstr(ptmi_version(), "ptmi") != NULL);
     CHECK(ptmi_create(0, NULL) == PTMI_ERR_INVALID);
     CHECK(strlen(ptmi_last_error(NULL)) > 0);
