@@ -63,8 +63,19 @@ def _worker(rank, world, port, mode, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     W, H, spp = 96, 80, 5
     a = torch.zeros((H, W, 3)); c = torch.zeros((H, W), dtype=torch.int32)
+    render_tiles = None
+    if mode == "tile_one_call":         # bench.py's render_c4 leg: a rank's tiles go down in ONE call (ptmi_render_tiles_dev)
+        mode = "tile"
+        calls = []
+
+        def render_tiles(accum, counts, tiles, spp_begin, spp_count):
+            calls.append(len(tiles))
+            for rect in tiles:
+                _fake_render_rect(accum, counts, rect, spp_begin, spp_count)
     sharded.render_sharded(_fake_render_rect, a, c, W, H, spp, rank=rank, world=world, dist=dist, dst=0, mode=mode,
-                           tile=32, render_rows=_fake_render_rows, row_block=8)
+                           tile=32, render_rows=_fake_render_rows, row_block=8, render_tiles=render_tiles)
+    if render_tiles is not None:
+        assert calls == [len(sharded.my_tiles(W, H, world, rank, 32))]
     if rank == 0:
         ra, rc = _single(W, H, spp)
         q.put((bool(torch.equal(a, ra)), bool(torch.equal(c, rc))))
@@ -72,7 +83,7 @@ def _worker(rank, world, port, mode, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["tile", "rows", "sample"])
+@pytest.mark.parametrize("mode", ["tile", "tile_one_call", "rows", "sample"])
 def test_reduce_matches_single_process(mode):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
