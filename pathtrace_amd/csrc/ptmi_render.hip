@@ -636,6 +636,9 @@ __global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, P
     const uint64_t n = sray_total(sn);
     if (n < vote_from || (uint64_t)blockIdx.x * WAVE >= n) return;
     TravCounters cnt;
+    // (Tried: a per-lane cache of the last occluding triangle, tested before the walk -- the answer cannot depend on which
+    // occluder is found.  connect 125.2 -> 124.3 ms per C3 frame, 171.1 -> 171.0 on the 10.4 M-triangle scene: the time
+    // goes into the unoccluded rays, which have to visit every box their segment overlaps whatever the order.)
     vote_walk<WAVE, true, COUNT, uint32_t>(
         bvh, smem + threadIdx.x, n, pl.qcnt + (size_t)QC_CURSOR * QC_STRIDE, refill_min, tri_bias, vote_chunk(n, chunk_max), cnt,
         [&](uint64_t idx, NextRay &nx, uint32_t &pos) {
@@ -667,6 +670,9 @@ __device__ __forceinline__ STri load_stri(const DevScene &sc, uint32_t prim) {
     t.mat = f2u(q4.z);
     return t;
 }
+// (Tried: a material record as four 16-byte loads instead of field-by-field dword loads through a reference: shade +13 ms
+// per C3 frame -- the kernels read 5-7 of its 16 words, and the bytes returned count as much as the instructions.)
+__device__ __forceinline__ const PtMaterial &load_material(const DevScene &sc, uint32_t i) { return sc.mats[i]; }
 __device__ __forceinline__ bool is_emissive(const PtMaterial &m) { return m.ke[0] > 0.0f || m.ke[1] > 0.0f || m.ke[2] > 0.0f; }
 
 // (re)derives the hit of a frame from what the frame stores: ray, t, primitive, and whether the glass branch flipped
@@ -747,7 +753,7 @@ __device__ __forceinline__ uint32_t direct_lighting(const DevScene &sc, const Re
                 float pdf_brdf = dot(h.dnormal, toLight) / PT_PI32;
                 float pdf_sa = pdf * (distance * distance) / sndorl;
                 float weight = mis_weight(pdf_sa, pdf_brdf);
-                V3 le = mk(sc.mats[e.mat].ke);
+                V3 le = mk(load_material(sc, e.mat).ke);
                 V3 brdf = scale(albedo, (float)(1.0 / 3.14159265358979323846));
                 ec = scale(cmul(le, brdf), geometryTerm * weight / pdf);
             }
@@ -761,7 +767,7 @@ __device__ __forceinline__ uint32_t direct_lighting(const DevScene &sc, const Re
 // GI rays, and the emitter seen directly.
 __device__ __forceinline__ V3 diffuse_final(const DevScene &sc, const RenderArgs &ra, uint32_t fmat, int bounces, int bindex, V3 direct,
                                             V3 gi_sum, V3 albedo) {
-    const PtMaterial &m = sc.mats[fmat];
+    const PtMaterial &m = load_material(sc, fmat);
     V3 indirect = bounces > 0 ? gi_sum : mk(0, 0, 0);
     V3 fin = direct;
     fin = add(fin, scale(albedo, ra.p.ambient));
@@ -778,7 +784,7 @@ __device__ __forceinline__ V3 combine_components(V3 diffuse, V3 reflective, V3 r
 }
 // HandleReflectiveMaterial's result once its rays are in (:716-721), plus the refraction TraceRay adds to it (:165, :211)
 __device__ __forceinline__ V3 reflective_final(const DevScene &sc, const RenderArgs &ra, uint32_t fmat, V3 sum, V3 refr) {
-    const PtMaterial &m = sc.mats[fmat];
+    const PtMaterial &m = load_material(sc, fmat);
     sum = scale(sum, 1.0f / (float)ra.p.scatter_rays);
     sum = cmul(sum, mk(m.ks));
     return add(sum, refr);
@@ -800,11 +806,26 @@ __device__ __forceinline__ V3 sum_free_terms(const Pool &pl, uint32_t &pneed, ui
     }
     return pdirect;
 }
-// shadow term k of a record (words 19.. are not 16-byte aligned: four dword loads from a line the lane has just read)
-__device__ __forceinline__ float4 rec_term(const Pool &pl, const float4 *rec, int k) {
-    if (k >= pl.rec_inline) return rec[REC_BASE / 4 + (k - pl.rec_inline)];
-    const float *w = (const float *)rec + R_TERMS + 4 * k;
-    return make_float4(w[0], w[1], w[2], w[3]);
+// The caller's direct lighting a RECORD carries.  The inline terms sit in words 19 .. 30 (not 16-byte aligned): the
+// record's second sector is read as four aligned 16-byte loads -- only when a term arrives -- and the terms are picked
+// out of them (twelve scattered dword loads per visit when measured against this: the vector-memory path is what the
+// shade kernels share with nothing to spare).
+__device__ __forceinline__ V3 sum_record_terms(const Pool &pl, const float4 *rec, uint32_t &pneed, uint32_t &err) {
+    if (pneed >> pl.nshadow) { err |= ERR_PHASE; pneed = 0; }
+    V3 pdirect = mk(0, 0, 0);
+    if (!pneed) return pdirect;
+    auto take = [&](float4 v) {
+        uint32_t qi = f2u(v.w);
+        if (qi >= pl.cap * (uint32_t)pl.nshadow) { err |= ERR_SLOT; qi = 0; }
+        if (pl.q_sray_occ[qi] == 0) pdirect = add(pdirect, mk(v.x, v.y, v.z));
+    };
+    const float4 q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+    if (pneed & 1u) take(make_float4(q4.w, q5.x, q5.y, q5.z));
+    if (pneed & 2u) take(make_float4(q5.w, q6.x, q6.y, q6.z));
+    if (pl.rec_inline > 2 && (pneed & 4u)) take(make_float4(q6.w, q7.x, q7.y, q7.z));
+    for (int k = pl.rec_inline; k < pl.nshadow; ++k)
+        if (pneed >> k & 1u) take(rec[REC_BASE / 4 + (k - pl.rec_inline)]);
+    return pdirect;
 }
 
 // States of the per-path machine inside one shade invocation.
@@ -965,7 +986,7 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
             uint32_t pneed = f2u(r3.y) >> 8;
             if (slot >= pl.cap) { err |= ERR_SLOT; slot = 0; }
             if (depth >= pl.nframes) { err |= ERR_DEPTH; depth = 0; }
-            pd = sum_free_terms(pl, pneed, err, [&](int k) { return rec_term(pl, rec, k); });
+            pd = sum_record_terms(pl, rec, pneed, err);
             if (status == (uint32_t)HS_HIT && !(ctx & CTX_FAIL)) err |= ERR_CLASS;          // a hit to shade does not belong here
             if (!(ctx & CTX_FAIL) && status == (uint32_t)HS_MISS && sc.sky.kind != PTMI_SKY_NONE)
                 ret = sky_sample(sc.sky, sc.sky_img, mk(r1.x, r1.y, r1.z));                 // :260-263
@@ -1030,7 +1051,7 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
             pd = mk(f1.w, f2.x, f2.y);
         }
         if (err) { atomicOr(&counter_shard(counters)[CNT_ERROR], (unsigned long long)err); ret = mk(0, 0, 0); }
-        float *o = pl.out + 3 * (size_t)(sid < ra.total ? sid : 0);
+        float *o = pl.out + 3 * (size_t)(sid < ra.total ? sid : 0);          // (one 12-byte store instead: shade +12 ms per C3 frame)
         o[0] = ret.x; o[1] = ret.y; o[2] = ret.z;
         to.finished = true; to.slot = slot;
     }
@@ -1087,7 +1108,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         const float energy = r3.z;
         trk0 = r3.w;
         const V3 ln = mk(r4.x, r4.y, r4.z);
-        const V3 pdirect = sum_free_terms(pl, pneed, err, [&](int k) { return rec_term(pl, rec, k); });
+        const V3 pdirect = sum_record_terms(pl, rec, pneed, err);
         if ((hitword >> 30) != (uint32_t)HS_HIT || bounces < 0 || energy < (float)1e-2) err |= ERR_CLASS;
         const int hprim = (int)(hitword & 0x3FFFFFFFu);
         const V3 cur_o = mk(r0.x, r0.y, r0.z), cur_d = mk(r1.x, r1.y, r1.z);
@@ -1284,7 +1305,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             in_ln = mk(r4.x, r4.y, r4.z);
             if (sc.has_bh) { const float2 v = ((const float2 *)rec)[R_VT / 2]; vt1 = v.x; vt0 = v.y; }
             if (slot >= pl.cap) { err |= ERR_SLOT; slot = 0; }
-            pdirect = sum_free_terms(pl, pneed, err, [&](int k) { return rec_term(pl, rec, k); });
+            pdirect = sum_record_terms(pl, rec, pneed, err);
         } else {
             const size_t k = shp_entry(pl, i - na, true);
             const float4 e0 = pl.q_shpath[cur][2 * k], e1 = pl.q_shpath[cur][2 * k + 1];
@@ -1526,7 +1547,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (state == ST_REFL_LOOP) {                                                            // :670-722
                 uint32_t fmat = FU(F_MAT);
                 if (fmat >= sc.nmats) { err |= ERR_MAT; fmat = 0; }
-                const PtMaterial &m = sc.mats[fmat];
+                const PtMaterial &m = load_material(sc, fmat);
                 const int bounces = f_bounces();
                 bool pushed = false;
                 while (f_s() < ra.p.scatter_rays) {
