@@ -191,7 +191,9 @@ struct Pool {
     int nframes, ntrk, nshadow;          // bounces+1, tracker history capacity (multiple of 4), nlights+2
     int rec_q;                           // float4s per extend-queue record (REC / 4; a multiple of 4: whole 64-byte sectors)
     int rec_inline;                      // shadow terms held in words 19.. of a record (the others from word 32 on)
-    float4 *fr;                          // [cap][nframes][8]   frames (F_*)
+    float4 *fr;                          // [cap][nframes][8]   frames (F_*).  (Tried: [slot][sector][depth], the first sectors of a path's frames side
+                                         // by side for the kernel that unwinds them: shade +4 ms per C3 frame -- two half-line writes at
+                                         // different times into one 128-byte line cost more than the neighbouring reads save.)
     float *trk;                          // [cap][ntrk]         RefractiveIndexTracker.indices 1 .. (entry 0 travels with the path)
     // queues
     float4 *q_rec[2];                    // extend queue (double buffered): one record per entry (R_*)
