@@ -276,7 +276,7 @@ extern "C" int ptmi_create(int device, ptmi_ctx **out) {
         if (const char *v = getenv("PTMI_PERSIST_WAVES_PER_CU")) ctx->persist_waves_per_cu = std::max(1, atoi(v));
         if (const char *v = getenv("PTMI_VOTE_REFILL_MIN")) ctx->vote_refill_min = std::max(1, std::min(64, atoi(v)));
         if (const char *v = getenv("PTMI_VOTE_TRI_BIAS")) ctx->vote_tri_bias = atoi(v);
-        if (const char *v = getenv("PTMI_POOL_PATHS")) ctx->pool_paths = std::max(1 << 16, std::min(1 << 26, atoi(v)));
+        if (const char *v = getenv("PTMI_POOL_PATHS")) ctx->pool_paths = std::max(1 << 16, std::min(1 << 28, atoi(v)));
         if (const char *v = getenv("PTMI_POOL_GIB")) ctx->pool_bytes_max = (uint64_t)std::max(1, atoi(v)) << 30;
         if (const char *v = getenv("PTMI_RENDER_LANES")) ctx->render_lanes = atoi(v);
         if (const char *v = getenv("PTMI_SHADE_SPLIT")) ctx->shade_split = atoi(v);

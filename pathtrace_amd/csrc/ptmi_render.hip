@@ -96,8 +96,8 @@ enum { L_RET = 0, L_DIFF = 1, L_GEN = 2,                                 // the 
        L_G_RET = L_GEN, L_G_GLASS, L_G_REFL, L_G_MID, L_G_EMIT, L_G_DIFF, L_G_OTHER, NLIST, N_GEN = NLIST - L_GEN };
 // what extend knows about a triangle's material (one byte per triangle, ptmi_upload_scene): tracer.go:49 / :95 / :116-118
 enum { TC_GLASS = 1, TC_ACCR = 2, TC_REFL = 4, TC_MID = 8, TC_EMIT = 16 };
-// what extend knows about the pending call (bits 26.. of the record's slot word)
-enum { CTX_SHIFT = 26, CTX_FAIL = 1, CTX_ANC = 2, CTX_B0 = 4, CTX_BI = 8, SLOT_MASK = (1 << CTX_SHIFT) - 1 };
+// what extend knows about the pending call (bits 28.. of the record's slot word: the pool has at most 2^28 slots)
+enum { CTX_SHIFT = 28, CTX_FAIL = 1, CTX_ANC = 2, CTX_B0 = 4, CTX_BI = 8, SLOT_MASK = (1 << CTX_SHIFT) - 1 };
 enum { QC_EXT0 = 0, QC_EXT1 = 1, QC_SHP0 = 2, QC_SHP1 = 3, QC_SHA0 = 4, QC_SHA1 = 5, QC_FREE = 6, QC_SRAY = 7, QC_NEXT = QC_SRAY + NSB,   // QC_NEXT: next sample id to generate
        QC_CURSOR = QC_NEXT + 1, QC_CURSOR_EXT = QC_CURSOR + 1,                  // ray cursors of the vote-scheduled kernels
        QC_LIST = QC_CURSOR_EXT + 1,                                             // lengths of the index lists (bin_kernel)
@@ -122,7 +122,7 @@ static_assert(sizeof(IterArgs) <= 128, "IterArgs is one line");
 //   for straight rays with up to three shadow-ray kinds), because the shade kernels gather records in class order and a
 //   gathered record must not share its sectors with another entry (a [field][entry] layout read through a permutation
 //   fetches every sector about twice).  Words:
-//      0-2  ray origin             3  slot | CTX_* << 26          4-6  ray direction       7  sample id
+//      0-2  ray origin             3  slot | CTX_* << 28          4-6  ray direction       7  sample id
 //      8-9  spare (extend's answer -- status << 30 | primitive, t -- goes to a dense array beside the queue, q_hit: an
 //           8-byte store into a record is a read-modify-write of its sector, extend +12 % when measured)
 //     10    RNG key     11  RNG counter
@@ -2148,21 +2148,18 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     }
     const uint64_t max_total = npix * spp_chunk;
     // Every wavefront iteration costs time that does not depend on the number of paths (the tails of three kernels
-    // that wait for their longest rays), so the pool is as large as the work and the memory budget allow: 2 M paths
-    // reach 640 Msamples/s on C3, 16 M reach 760 (profiles/r01c/README.md).
+    // that wait for their longest rays), so the pool is as large as the work and the memory budget allow: on C3 at
+    // 256 spp 32 M paths reach 1540 Msamples/s, 64 M 1640, 128 M with the frame in one pass 1730.
     const bool curved = rs->has_bh != 0;
     const uint64_t path_bytes = pool_bytes_per_path(bounces, (int)rs->nlights, curved);
     const uint64_t by_targets = 0xFFFFFFFFull / ((uint64_t)(bounces + 1) * (rs->nlights + 2));   // shadow-ray queue positions are 32-bit
     const uint64_t by_budget = std::min(by_targets, std::max<uint64_t>(1u << 16, ctx->pool_bytes_max / path_bytes));
     // Two independent loops ("lanes"), each on half of the pool and of the samples and on a stream of its own, when
     // there is work for both: shade waits on memory most of the time while extend and connect keep the VALUs busy, so
-    // one lane's traversal kernels fill the tails of the other's shade (shade's LDS leaves no room for more overlap
-    // than that).  Measured: +3 % on C3, +8 % on C1, +1 % on the black-hole march, nothing with an 88 MB tree, -2 % with
-    // a 672 MB tree (two kernels' working sets in the caches instead of one), so by default (render_lanes < 0) two
-    // lanes run when the packed tree fits the L2s (8 x 4 MB); three lanes are 4 % slower than two on C3, four 9 % (each
-    // lane's queues get shorter).  The image does not depend on the split.
-    const uint64_t tree_bytes = ctx->packed_inner * 64 + ctx->packed_tris * 48;
-    const int want_lanes = ctx->render_lanes < 0 ? (tree_bytes <= (32ull << 20) ? 2 : 1) : ctx->render_lanes;
+    // one lane's traversal kernels fill the tails of the other's shade.  Measured on one box with the 128 M-path pool
+    // (C3, 256 spp: 1633 / 1712 / 1701 / 1637 Msamples/s with 1 / 2 / 3 / 4 lanes; the 672 MB tree at 4K: 853 / 865 /
+    // 870), so two lanes by default (render_lanes < 0) whatever the tree.  The image does not depend on the split.
+    const int want_lanes = ctx->render_lanes < 0 ? 2 : ctx->render_lanes;
     const int lanes = (want_lanes >= 2 && max_total >= (1ull << 22) && !ctx->profiling) ? std::min(want_lanes, (int)RenderState::MAX_LANES) : 1;
     uint32_t cap = (uint32_t)std::min<uint64_t>({(max_total + lanes - 1) / lanes, (uint64_t)ctx->pool_paths / lanes, by_budget / lanes});
     cap = (cap + 255) / 256 * 256;
