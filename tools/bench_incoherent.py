@@ -4,7 +4,7 @@ Infinity Cache (10 M triangles, 0.67 GB packed) with INCOHERENT rays -- origins 
 the sphere, batch order random -- so that neighbouring lanes and waves touch unrelated subtrees and only the top of the
 tree stays cached.  Prints Mrays/s, the counted work (N_inner, N_tri) and the algorithmic GB/s; under `rocprofv3 --pmc`
 (tools/pmc_incoherent.sh) the same launches give the fabric bytes and the L2 hit rate.
-usage: tools/bench_incoherent.py [--tris N] [--rays N] [--steps K] [--check]"""
+usage: tools/bench_incoherent.py [--tris N] [--rays N] [--steps K]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,7 +16,6 @@ from helpers import random_rays
 ap = argparse.ArgumentParser()
 ap.add_argument("--tris", type=int, default=10_000_000); ap.add_argument("--rays", type=int, default=1 << 24)
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--tmax", type=float, default=1000.0)
-ap.add_argument("--check", action="store_true", help="compare every 1024th ray with the CPU oracle")
 a = ap.parse_args()
 t0 = time.time()
 verts, tris = scenes.make_soup(a.tris, seed=42)
@@ -42,11 +41,4 @@ ms = e0.elapsed_time(e1) / a.steps
 print(f"extend_vote_kernel: {ms:.3f} ms per launch = {a.rays / ms / 1e3:.1f} Mrays/s; hit rate {(P >= 0).float().mean().item():.3f}; "
       f"per ray {c.inner_visits / a.rays:.2f} inner nodes, {c.tri_tests / a.rays:.2f} triangles = {alg / a.rays:.0f} B; "
       f"algorithmic {alg / 1e9:.2f} GB per launch = {alg / ms / 1e6:.0f} GB/s = {alg / ms / 1e6 / 8000:.3f} of the 8 TB/s HBM peak")
-if a.check:
-    import oracle_lib
-    orc = oracle_lib.OracleBVH(verts, tris, linear=box.linear())
-    idx = np.arange(0, a.rays, 1024)
-    op, ot, _ = orc.closest_hit(np.ascontiguousarray(o[idx]), np.ascontiguousarray(d[idx]), a.tmax, nthreads=16, counters=False)
-    gp, gt = P.cpu().numpy()[idx], t.cpu().numpy()[idx]
-    print(f"parity on every 1024th ray: {int((gp != op).sum()) + int((gt.view(np.uint32) != ot.view(np.uint32)).sum())} mismatches of {len(idx)}")
 ctx.close()

@@ -1,11 +1,11 @@
 #!/bin/bash
-# HBM-bound leg: tools/bench_incoherent.py plain (with parity check), then under the two PMC passes the guide prescribes.
+# HBM-bound leg: tools/bench_incoherent.py plain, then under the two PMC passes the guide prescribes.
 # usage: tools/pmc_incoherent.sh <outdir>
 set -u
 OUT=${1:-gpurun_out/incoherent}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-timeout -k 10 400 python3 tools/bench_incoherent.py --check > "$OUT/plain.txt" 2>&1 || { echo "plain run failed"; tail -5 "$OUT/plain.txt"; exit 1; }
+timeout -k 10 400 python3 tools/bench_incoherent.py > "$OUT/plain.txt" 2>&1 || { echo "plain run failed"; tail -5 "$OUT/plain.txt"; exit 1; }
 timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/bench_incoherent.py --steps 3 > "$OUT/pmc_fetch.log" 2>&1 || { echo "pmc_fetch failed"; tail -5 "$OUT/pmc_fetch.log"; exit 1; }
 timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -- python3 tools/bench_incoherent.py --steps 3 > "$OUT/pmc_write.log" 2>&1 || { echo "pmc_write failed"; tail -5 "$OUT/pmc_write.log"; exit 1; }
 python3 - "$OUT" <<'PY'
