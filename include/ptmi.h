@@ -274,6 +274,18 @@ int ptmi_render_samples(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *p
 int ptmi_to_rgba(ptmi_ctx *ctx, const float *accum_rgb, const uint32_t *counts, int32_t width, int32_t height,
                  uint8_t *rgba);
 
+/* No counterpart in the reference (its working set is the goroutines' stacks).  The integrator keeps its paths in a
+ * pool of device memory that is sized for the call -- as many paths as the call has samples, up to max_paths paths and
+ * max_bytes bytes (about 1 KB per path with bounces = 2 and two lights) -- and kept for the next call.  Every wavefront
+ * iteration has a cost that does not depend on the number of paths in it, so the defaults are generous (2^27 paths,
+ * 160 GiB of the 288 GB: C3 at 256 spp runs 11 % faster than with a quarter of that); a host that shares the GPU
+ * sets its own limits here (0 keeps a value; at least 2^16 paths and 64 MiB).  The image does not depend on the pool's
+ * size.  A pool already over the new limit is given back at once (the call synchronises the device).  When device
+ * memory is short a render call halves its pool until it fits, so the limit is a ceiling, not a reservation.
+ * ptmi_pool_info reports the pool in place (0, 0 before the first render call). */
+int ptmi_set_pool_limit(ptmi_ctx *ctx, uint64_t max_paths, uint64_t max_bytes);
+int ptmi_pool_info(ptmi_ctx *ctx, uint64_t *paths, uint64_t *bytes);
+
 /* Per-kernel timing of the render calls -- the counterpart of the reference's runtime/pprof CPU profile around its
  * workers (main.go:797-822).  While enabled, every kernel launch of the wavefront loop is bracketed by a pair of HIP
  * events on its stream, a pass runs as ONE loop (so that the kernels do not overlap and their times add up to the

@@ -2153,7 +2153,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     const bool curved = rs->has_bh != 0;
     const uint64_t path_bytes = pool_bytes_per_path(bounces, (int)rs->nlights, curved);
     const uint64_t by_targets = 0xFFFFFFFFull / ((uint64_t)(bounces + 1) * (rs->nlights + 2));   // shadow-ray queue positions are 32-bit
-    const uint64_t by_budget = std::min(by_targets, std::max<uint64_t>(1u << 16, ctx->pool_bytes_max / path_bytes));
+    const uint64_t by_budget = std::min(by_targets, std::max<uint64_t>(1u << 12, (ctx->pool_bytes_max - (1u << 20)) / path_bytes));   // 1 MiB: counters, alignment
     // Two independent loops ("lanes"), each on half of the pool and of the samples and on a stream of its own, when
     // there is work for both: shade waits on memory most of the time while extend and connect keep the VALUs busy, so
     // one lane's traversal kernels fill the tails of the other's shade.  Measured on one box with the 128 M-path pool
@@ -2161,8 +2161,9 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     // 870), so two lanes by default (render_lanes < 0) whatever the tree.  The image does not depend on the split.
     const int want_lanes = ctx->render_lanes < 0 ? 2 : ctx->render_lanes;
     const int lanes = (want_lanes >= 2 && max_total >= (1ull << 22) && !ctx->profiling) ? std::min(want_lanes, (int)RenderState::MAX_LANES) : 1;
-    uint32_t cap = (uint32_t)std::min<uint64_t>({(max_total + lanes - 1) / lanes, (uint64_t)ctx->pool_paths / lanes, by_budget / lanes});
-    cap = (cap + 255) / 256 * 256;
+    // what the work asks for, rounded up; what the limits allow, rounded down (ptmi_set_pool_limit's are ceilings)
+    const uint64_t cap_limit = std::max<uint64_t>(256, std::min<uint64_t>((uint64_t)ctx->pool_paths, by_budget) / lanes / 256 * 256);
+    uint32_t cap = (uint32_t)std::min<uint64_t>(((max_total + lanes - 1) / lanes + 255) / 256 * 256, cap_limit);
     // the per-sample output buffer is in place (above); now as large a pool as fits
     int rc;
     while ((rc = ensure_pool(ctx, cap, bounces, lanes, curved)) == PTMI_ERR_OOM && cap > (1u << 16))
@@ -2470,6 +2471,28 @@ extern "C" int ptmi_to_rgba(ptmi_ctx *ctx, const float *accum_rgb, const uint32_
             }
             o[3] = 255;
         }
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_set_pool_limit(ptmi_ctx *ctx, uint64_t max_paths, uint64_t max_bytes) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_set_pool_limit: ctx is null");
+    if (max_paths) ctx->pool_paths = (int)std::max<uint64_t>(1u << 16, std::min<uint64_t>(max_paths, 1u << 28));
+    if (max_bytes) ctx->pool_bytes_max = std::max<uint64_t>(max_bytes, 64ull << 20);
+    RenderState *rs = ctx->render;
+    if (rs && rs->pool_mem && (rs->pool_bytes > ctx->pool_bytes_max || (uint64_t)rs->pool_cap * rs->pool_lanes > (uint64_t)ctx->pool_paths)) {
+        PTMI_HIP(ctx, hipSetDevice(ctx->device));      // the pool in place is over the new limit: give it back now
+        PTMI_HIP(ctx, hipDeviceSynchronize());
+        (void)hipFree(rs->pool_mem);
+        rs->pool_mem = nullptr; rs->pool_bytes = 0; rs->pool_cap = 0;
+    }
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_pool_info(ptmi_ctx *ctx, uint64_t *paths, uint64_t *bytes) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_pool_info: ctx is null");
+    const RenderState *rs = ctx->render;
+    if (paths) *paths = rs && rs->pool_mem ? (uint64_t)rs->pool_cap * rs->pool_lanes : 0;
+    if (bytes) *bytes = rs && rs->pool_mem ? (uint64_t)rs->pool_bytes : 0;
     return PTMI_OK;
 }
 

@@ -121,6 +121,16 @@ class Renderer:
         check(self._lib.ptmi_upload_textures(self.ctx.handle, _ptr(uv, C.c_float), len(textures), _ptr(w, C.c_int32),
                                              _ptr(h, C.c_int32), _ptr(px, C.c_uint32)), self.ctx.handle)
 
+    def set_pool_limit(self, max_paths=0, max_bytes=0):
+        """Ceiling of the integrator's path pool (ptmi_set_pool_limit; 0 keeps a value).  The image does not depend on it."""
+        check(self._lib.ptmi_set_pool_limit(self.ctx.handle, int(max_paths), int(max_bytes)), self.ctx.handle)
+
+    def pool_info(self):
+        """(paths, bytes) of the pool in place."""
+        n, b = C.c_uint64(0), C.c_uint64(0)
+        check(self._lib.ptmi_pool_info(self.ctx.handle, C.byref(n), C.byref(b)), self.ctx.handle)
+        return int(n.value), int(b.value)
+
     def set_profiling(self, enabled=True):
         """Per-kernel HIP-event timing of the render calls (the reference's pprof hook, main.go:797-822); resets the totals."""
         check(self._lib.ptmi_set_profiling(self.ctx.handle, 1 if enabled else 0), self.ctx.handle)

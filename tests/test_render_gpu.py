@@ -436,6 +436,47 @@ def test_two_lanes_equal_one(monkeypatch):
             assert torch.equal(frames[0][0], a) and torch.equal(frames[0][1], c)
 
 
+def test_pool_limit_does_not_change_the_image():
+    """ptmi_set_pool_limit: a frame rendered through a 2^16-path pool (many passes over the free list) has the sums of
+    the same frame rendered with the default pool, bit for bit; the pool in place respects the limit, and lowering the
+    limit under it gives the memory back."""
+    import torch
+    from pathtrace_amd import Context
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    dev = torch.device("cuda", 0)
+    W, H, spp = 320, 200, 9
+    p = make_params(W, H, bounces=2, seed=11)
+    frames = []
+    for limit in (None, (1 << 16, 0), (0, 64 << 20)):
+        ctx = Context(0)
+        try:
+            r = Renderer(sc, ctx=ctx)
+            assert r.pool_info() == (0, 0)
+            if limit:
+                r.set_pool_limit(*limit)
+            a = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+            c = torch.zeros((H, W), dtype=torch.int32, device=dev)
+            r.render_device(a, c, p, sc.camera, spp=spp)
+            paths, nbytes = r.pool_info()
+            assert paths > 0 and nbytes > 0
+            if limit and limit[0]:
+                assert paths <= limit[0]
+            if limit and limit[1]:
+                assert nbytes <= limit[1]
+            if limit is None:
+                assert paths >= W * H * spp
+                r.set_pool_limit(1 << 16, 0)                         # under the pool in place: released at once
+                assert r.pool_info() == (0, 0)
+                a2 = torch.zeros_like(a); c2 = torch.zeros_like(c)
+                r.render_device(a2, c2, p, sc.camera, spp=spp)
+                assert torch.equal(a, a2) and torch.equal(c, c2) and r.pool_info()[0] <= 1 << 16
+            frames.append((a.cpu(), c.cpu()))
+        finally:
+            ctx.close()
+    for a, c in frames[1:]:
+        assert torch.equal(frames[0][0], a) and torch.equal(frames[0][1], c)
+
+
 def test_full_size_frame_properties(gpu_ctx):
     """BASELINE.json configs[2] geometry at full resolution (1920x1080, C3 scene, 16 M-path pool), checked through
     properties: a re-run is bit-identical (queue order and atomics play no part in the sums), two half sample
