@@ -2029,11 +2029,13 @@ static void prof_collect(ptmi_ctx *ctx) {
 }
 
 // One iteration of the wavefront loop on queue buffer `cur`, enqueued without knowing its sizes (IterArgs); the grids
-// cover the most paths the call can have in flight (the pool, or all of the call's samples if those are fewer).
+// cover the most paths the call can have in flight (the pool, or all of the call's samples if those are fewer, or
+// `live_bound`: what the host last saw alive or not yet started -- that number only falls, so an old look is a bound;
+// it is what keeps the draining iterations from launching a pool's worth of workgroups that leave at once).
 template <int STACK, bool COUNT>
 static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, const BinMap &bm, uint64_t lane_total,
-                               int cur, hipStream_t s) {
-    const uint64_t most = std::min<uint64_t>(pl.cap, lane_total);
+                               uint64_t live_bound, int cur, hipStream_t s) {
+    const uint64_t most = std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)pl.cap, lane_total, live_bound}));
     const unsigned cap_wgs = (unsigned)((most + 255) / 256), cap_waves = (unsigned)((most + WAVE - 1) / WAVE);
     if (ctx->profiling) ctx->prof_iterations++;
     timed(ctx, PROF_PREPARE, s, [&] {
@@ -2090,15 +2092,15 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
     return PTMI_OK;
 }
 static int enqueue_iteration(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, const RenderArgs &ra, const BinMap &bm, uint64_t lane_total,
-                             int cur, hipStream_t s) {
+                             uint64_t live_bound, int cur, hipStream_t s) {
     const int dep = ctx->stack_entries();
-    if (dep <= 16) return ctx->counting ? enqueue_iteration_t<16, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<16, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
-    if (dep <= 20) return ctx->counting ? enqueue_iteration_t<20, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<20, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
-    if (dep <= 24) return ctx->counting ? enqueue_iteration_t<24, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<24, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
-    if (dep <= 28) return ctx->counting ? enqueue_iteration_t<28, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<28, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
-    if (dep <= 32) return ctx->counting ? enqueue_iteration_t<32, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<32, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
-    if (dep <= 48) return ctx->counting ? enqueue_iteration_t<48, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<48, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
-    return ctx->counting ? enqueue_iteration_t<64, true>(ctx, pl, sc, ra, bm, lane_total, cur, s) : enqueue_iteration_t<64, false>(ctx, pl, sc, ra, bm, lane_total, cur, s);
+    if (dep <= 16) return ctx->counting ? enqueue_iteration_t<16, true>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s) : enqueue_iteration_t<16, false>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s);
+    if (dep <= 20) return ctx->counting ? enqueue_iteration_t<20, true>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s) : enqueue_iteration_t<20, false>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s);
+    if (dep <= 24) return ctx->counting ? enqueue_iteration_t<24, true>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s) : enqueue_iteration_t<24, false>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s);
+    if (dep <= 28) return ctx->counting ? enqueue_iteration_t<28, true>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s) : enqueue_iteration_t<28, false>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s);
+    if (dep <= 32) return ctx->counting ? enqueue_iteration_t<32, true>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s) : enqueue_iteration_t<32, false>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s);
+    if (dep <= 48) return ctx->counting ? enqueue_iteration_t<48, true>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s) : enqueue_iteration_t<48, false>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s);
+    return ctx->counting ? enqueue_iteration_t<64, true>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s) : enqueue_iteration_t<64, false>(ctx, pl, sc, ra, bm, lane_total, live_bound, cur, s);
 }
 
 // Renders samples [spp_begin, spp_begin+spp_count) of the rectangle into d_out chunks and accumulates them
@@ -2226,7 +2228,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         const size_t qc_words = (size_t)QC_COUNT * QC_STRIDE;
         const int iters_per_batch = std::max(1, ctx->render_batch_iters);
         struct Lane {
-            Pool pl; RenderArgs ra; hipStream_t st; uint64_t total; int cur = 0; bool active = true;
+            Pool pl; RenderArgs ra; hipStream_t st; uint64_t total; uint64_t bound = ~0ull; int cur = 0; bool active = true;
             unsigned long long *hc; hipEvent_t *ev;
         } L[RenderState::MAX_LANES];
         ra.nlanes = (uint32_t)lanes;
@@ -2251,7 +2253,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         }
         auto enqueue_batch = [&](Lane &ln, int slot) -> int {
             for (int k = 0; k < iters_per_batch; ++k) {
-                int r = enqueue_iteration(ctx, ln.pl, sc, ln.ra, bm, ln.total, ln.cur, ln.st);
+                int r = enqueue_iteration(ctx, ln.pl, sc, ln.ra, bm, ln.total, ln.bound, ln.cur, ln.st);
                 if (r) return r;
                 ln.cur ^= 1;
             }
@@ -2279,7 +2281,11 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
                 const unsigned long long *hc = ln.hc + (size_t)slot * qc_words;
                 const unsigned long long left = hc[(QC_EXT0 + cur_then[l]) * QC_STRIDE] + hc[(QC_SHP0 + cur_then[l]) * QC_STRIDE] +
                                                 hc[(QC_SHA0 + cur_then[l]) * QC_STRIDE];
-                if (left == 0 && hc[QC_NEXT * QC_STRIDE] >= ln.total) ln.active = false;
+                const unsigned long long started = std::min<unsigned long long>(hc[QC_NEXT * QC_STRIDE], ln.total);
+                if (left == 0 && started >= ln.total) ln.active = false;
+                // every sample is either not started, alive in one of the three queues, or done: an upper bound of what
+                // any later iteration can hold
+                if (ctx->render_shrink_grids) ln.bound = std::min<uint64_t>(ln.bound, left + (ln.total - started));
             }
         }
         for (int l = 1; l < lanes; ++l) {
