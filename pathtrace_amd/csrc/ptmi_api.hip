@@ -287,6 +287,7 @@ extern "C" int ptmi_create(int device, ptmi_ctx **out) {
         if (const char *v = getenv("PTMI_RENDER_VOTE_REFILL_MIN")) ctx->render_vote_refill_min = std::max(1, std::min(64, atoi(v)));
         if (const char *v = getenv("PTMI_RENDER_VOTE_CHUNK")) ctx->render_vote_chunk = std::max(64, atoi(v) / 64 * 64);
         if (const char *v = getenv("PTMI_EXTEND_VOTE")) ctx->extend_vote = atoi(v);
+        if (const char *v = getenv("PTMI_IMPLICIT_FRESH")) ctx->implicit_fresh = atoi(v);
         if (const char *v = getenv("PTMI_SHRINK_GRIDS")) ctx->render_shrink_grids = atoi(v);
         if (const char *v = getenv("PTMI_CHUNK_MSAMPLES")) ctx->chunk_msamples = std::max(1, std::min(1024, atoi(v)));
         if (const char *v = getenv("PTMI_VOTE_CHUNK")) ctx->vote_chunk = std::max(64, atoi(v) / 64 * 64);

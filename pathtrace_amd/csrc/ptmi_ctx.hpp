@@ -76,6 +76,7 @@ struct ptmi_ctx {
     int num_cus = 256;
     int pool_paths = 1 << 27;           // most paths in flight in the integrator's pool ...
     uint64_t pool_bytes_max = 160ull << 30;  // ... and most device memory the pool may take (of 288 GB; ~1 KB per path)
+    int implicit_fresh = 1;             // fresh samples without queue records where extend never writes into one (straight single-segment rays)
     int render_shrink_grids = 1;        // size the draining iterations' grids by the paths the host last saw alive
     int chunk_msamples = 1024;          // samples per pass over the region, in 2^20 (bounds the per-sample output buffer: 12 B each)
     int extend_vote = 1;                // extend (straight rays, one segment per call) as a vote-scheduled persistent kernel (0: one-shot)

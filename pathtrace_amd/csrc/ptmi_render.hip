@@ -171,6 +171,11 @@ struct RenderArgs {
     // The samples of a pass are dealt to `nlanes` independent wavefront loops in blocks of LANE_BLOCK sample ids, round
     // robin: sample j of lane `lane` is sample id ((j / LANE_BLOCK) * nlanes + lane) * LANE_BLOCK + j % LANE_BLOCK.
     uint32_t lane, nlanes;
+    // fresh samples are not written into the extend queue as records: generate writes their rays into a dense array for
+    // extend (32 bytes each; making the ray up inside the persistent walk's refill step stalls the wave: extend +13 %)
+    // and shade makes up the record of entry gen_base + j on the spot (fresh_head).  Set for straight single-segment
+    // rays (extend never moves such a ray, so it has nothing to write back into the record).
+    uint32_t implicit_fresh;
 };
 enum { LANE_BLOCK_LOG2 = 16, LANE_BLOCK = 1 << LANE_BLOCK_LOG2 };
 __host__ __device__ inline uint64_t lane_sample_id(uint64_t j, uint32_t lane, uint32_t nlanes) {
@@ -204,7 +209,9 @@ struct Pool {
     float4 *q_shp_sh[2];                 // ... their shadow terms: nshadow x (term.xyz, bits(position of the ray))
     float4 *q_sray_a, *q_sray_b;         // shadow rays: (o.xyz, range) / (d.xyz, -)
     uint8_t *q_sray_occ;                 // connect's answers, by position in the shadow-ray queue (0 free, 1 occluded)
-    uint32_t *q_free;                    // slots that finished in the last shade pass
+    float4 *q_fresh_a, *q_fresh_b;       // rays of this iteration's fresh samples, dense ((o, slot | ctx), (d, sample id)): what extend reads of them
+    uint32_t *q_free[2];                 // slots that finished in the last shade pass (double buffered like the queues: this
+                                         // iteration's fresh samples take theirs from [cur], shade fills [cur ^ 1])
     unsigned long long *qcnt;            // QC_COUNT counters, QC_STRIDE words apart
     IterArgs *it;                        // this iteration's arguments (iter_prep_kernel)
     float *out;                          // per-sample radiance [total][3]
@@ -256,7 +263,7 @@ __device__ __forceinline__ void region_pixel(const RenderArgs &ra, uint32_t pix,
 // Start of a call: every slot is free, nothing is queued.
 __global__ __launch_bounds__(256) void iter_init_kernel(Pool pl, uint32_t n0) {
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += stride) pl.q_free[i] = i;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += stride) pl.q_free[0][i] = i;
     if (blockIdx.x == 0 && threadIdx.x < QC_COUNT) pl.qcnt[(size_t)threadIdx.x * QC_STRIDE] = threadIdx.x == QC_FREE ? n0 : 0ull;
 }
 
@@ -372,43 +379,73 @@ __device__ __forceinline__ uint32_t pack_call(int depth, uint32_t trk_len, int b
     return ((uint32_t)depth & 0xFFu) | (trk_len & 0xFFu) << 8 | ((uint32_t)bounces & 0xFFu) << 16 | ((uint32_t)bindex & 0xFFu) << 24;
 }
 
-// A fresh sample is a pending call and nothing else: one record at the end of the extend queue (no atomic: entry
-// gen_base + i), written as whole sectors; its slot comes from the free list.
+// A fresh sample is a pending call and nothing else.  The first sector of its record (the whole record: FL_SHORT) --
+// main.go:862-875: the camera ray, bounceIndex 0, lastSurfaceNormal {}, not specular, NewRefractiveIndexTracker(1.0),
+// energy 1.0; TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0 (CTX_FAIL).  Fresh sample j of the
+// iteration is entry gen_base + j of the extend queue and takes slot q_free[cur][j].
+struct RecHead { float4 r0, r1, r2, r3; };
+__device__ __forceinline__ RecHead fresh_head(const Pool &pl, const RenderArgs &ra, int cur, uint32_t j) {
+    const uint32_t slot = pl.q_free[cur][j];
+    const uint32_t sid = (uint32_t)lane_sample_id(pl.it->first_sample + j, ra.lane, ra.nlanes);   // total < 2^32/3 (render_core)
+    const uint32_t pix = sid / ra.spp_chunk, smp = sid % ra.spp_chunk;
+    int X, Y;
+    region_pixel(ra, pix, X, Y);
+    Rng rng = rng_init(ra.p.seed, (uint32_t)(Y * ra.p.width + X), ra.spp_begin + smp);
+    const float rx = ((float)X + rng_f32(rng)) / (float)ra.p.width;
+    const float ry = ((float)Y + rng_f32(rng)) / (float)ra.p.height;
+    const float px = (rx - 0.5f) * 2.0f, py = (ry - 0.5f) * 2.0f;
+    const V3 pos = mk(ra.cam.position), fwd = mk(ra.cam.forward), right = mk(ra.cam.right), up = mk(ra.cam.up);
+    const V3 rayOrigin = add(add(add(pos, scale(fwd, ra.cam.frustum_distance)), scale(up, py)), scale(right, px));
+    const V3 d = normalize(mk(rayOrigin.x - pos.x, rayOrigin.y - pos.y, rayOrigin.z - pos.z));
+    RecHead h;
+    h.r0 = make_float4(pos.x, pos.y, pos.z, u2f(slot | call_ctx(ra.p.bounces, 0, 1.0f, 0u) << CTX_SHIFT));
+    h.r1 = make_float4(d.x, d.y, d.z, u2f(sid));
+    h.r2 = make_float4(0.0f, 0.0f, u2f(rng.key), u2f(rng.ctr));                                  // R_HIT, R_T spare; R_KEY, R_CTR
+    h.r3 = make_float4(u2f(pack_call(0, 1u, ra.p.bounces, 0)), u2f((uint32_t)FL_SHORT), 1.0f, 1.0f);   // depth 0, tracker {1.0}; no terms; energy; trk0
+    return h;
+}
+// The first sector of entry e of the extend queue: from its record, or made up for a fresh sample that has none.
+__device__ __forceinline__ RecHead call_head(const Pool &pl, const RenderArgs &ra, int cur, uint32_t e) {
+    const uint32_t gen_base = pl.it->gen_base;
+    if (ra.implicit_fresh && e >= gen_base) return fresh_head(pl, ra, cur, e - gen_base);
+    const float4 *rec = rec_at(pl, cur, e);
+    RecHead h;
+    h.r0 = rec[0]; h.r1 = rec[1]; h.r2 = rec[2]; h.r3 = rec[3];
+    return h;
+}
+// ... and the ray alone (extend)
+__device__ __forceinline__ void call_ray(const Pool &pl, const RenderArgs &ra, int cur, uint32_t e, float4 &qa, float4 &qb) {
+    const uint32_t gen_base = pl.it->gen_base;
+    if (ra.implicit_fresh && e >= gen_base) { qa = pl.q_fresh_a[e - gen_base]; qb = pl.q_fresh_b[e - gen_base]; return; }
+    const float4 *rec = rec_at(pl, cur, e);
+    qa = rec[0]; qb = rec[1];
+}
+// The fresh samples' rays for extend (implicit_fresh), or, where extend does write into records (a marched or curved
+// ray), their records: one sector each at the end of the extend queue (no atomic: entry gen_base + i), written as
+// whole sectors.
+__global__ __launch_bounds__(256) void generate_rays_kernel(Pool pl, RenderArgs ra, int cur) {
+    const uint32_t n = pl.it->gen_n;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const RecHead h = fresh_head(pl, ra, cur, i);
+        pl.q_fresh_a[i] = h.r0; pl.q_fresh_b[i] = h.r1;
+    }
+}
 __global__ __launch_bounds__(256) void generate_kernel(Pool pl, RenderArgs ra, int cur) {
     // the 256 records a workgroup writes per trip are contiguous, so they are put together in LDS ([word][thread]) and
     // written out as whole lines (per-thread 16-byte stores 128 bytes apart reach 3.2 TB/s)
     __shared__ float s_rec[16 * 256];
     const uint32_t n = pl.it->gen_n, q_base = pl.it->gen_base;
-    const unsigned long long first_sample = pl.it->first_sample;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
         const uint32_t i = i0 + threadIdx.x;
         float4 *dst = nullptr;
         if (i < n) {
-            const uint32_t slot = pl.q_free[i];
-            const uint32_t sid = (uint32_t)lane_sample_id(first_sample + i, ra.lane, ra.nlanes);   // total < 2^32/3 (render_core)
-            const uint32_t pix = sid / ra.spp_chunk, smp = sid % ra.spp_chunk;
-            int X, Y;
-            region_pixel(ra, pix, X, Y);
-            Rng rng = rng_init(ra.p.seed, (uint32_t)(Y * ra.p.width + X), ra.spp_begin + smp);
-            const float rx = ((float)X + rng_f32(rng)) / (float)ra.p.width;
-            const float ry = ((float)Y + rng_f32(rng)) / (float)ra.p.height;
-            const float px = (rx - 0.5f) * 2.0f, py = (ry - 0.5f) * 2.0f;
-            const V3 pos = mk(ra.cam.position), fwd = mk(ra.cam.forward), right = mk(ra.cam.right), up = mk(ra.cam.up);
-            const V3 rayOrigin = add(add(add(pos, scale(fwd, ra.cam.frustum_distance)), scale(up, py)), scale(right, px));
-            const V3 d = normalize(mk(rayOrigin.x - pos.x, rayOrigin.y - pos.y, rayOrigin.z - pos.z));
-            // main.go:875: bounceIndex 0, lastSurfaceNormal {}, not specular, NewRefractiveIndexTracker(1.0), energy 1.0.
-            // TraceRay's entry test (tracer.go:16) can only fail here for bounces < 0 (CTX_FAIL).
+            const RecHead h = fresh_head(pl, ra, cur, i);
             float *w = s_rec + threadIdx.x;
-            w[R_O * 256] = pos.x; w[(R_O + 1) * 256] = pos.y; w[(R_O + 2) * 256] = pos.z;
-            w[R_SLOT * 256] = u2f(slot | call_ctx(ra.p.bounces, 0, 1.0f, 0u) << CTX_SHIFT);
-            w[R_D * 256] = d.x; w[(R_D + 1) * 256] = d.y; w[(R_D + 2) * 256] = d.z;
-            w[R_SID * 256] = u2f(sid);
-            w[R_HIT * 256] = 0.0f; w[R_T * 256] = 0.0f;
-            w[R_KEY * 256] = u2f(rng.key); w[R_CTR * 256] = u2f(rng.ctr);
-            w[R_PACK * 256] = u2f(pack_call(0, 1u, ra.p.bounces, 0));                                  // depth 0, tracker {1.0}
-            w[R_FLAGS * 256] = u2f((uint32_t)FL_SHORT);             // lastSurfaceNormal {} and no terms: the first sector is the record
-            w[R_ENERGY * 256] = 1.0f; w[R_TRK0 * 256] = 1.0f;
+            const float4 q[4] = {h.r0, h.r1, h.r2, h.r3};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { w[(4 * k) * 256] = q[k].x; w[(4 * k + 1) * 256] = q[k].y; w[(4 * k + 2) * 256] = q[k].z; w[(4 * k + 3) * 256] = q[k].w; }
             dst = rec_at(pl, cur, (size_t)q_base + i);
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own LDS writes, before its lanes read them
@@ -453,7 +490,8 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
         const uint32_t i = base + threadIdx.x;
         if (i >= n) continue;
         float4 *rec = rec_at(pl, cur, i);
-        const float4 qa = rec[0], qb = rec[1];
+        float4 qa, qb;
+        call_ray(pl, ra, cur, i, qa, qb);
         V3 o = mk(qa.x, qa.y, qa.z);
         V3 d = mk(qb.x, qb.y, qb.z);
         RayState st = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -518,8 +556,8 @@ __global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Po
     vote_walk<WAVE, false, COUNT, ExtTag, true>(
         bvh, smem + threadIdx.x, n, pl.qcnt + (size_t)QC_CURSOR_EXT * QC_STRIDE, refill_min, tri_bias, vote_chunk(n, chunk_max), cnt,
         [&](uint64_t idx, NextRay &nx, ExtTag &tag) {
-            const float4 *rec = rec_at(pl, cur, idx);
-            const float4 qa = rec[0], qb = rec[1];
+            float4 qa, qb;
+            call_ray(pl, ra, cur, (uint32_t)idx, qa, qb);
             tag.entry = (uint32_t)idx; tag.ctx = f2u(qa.w) >> CTX_SHIFT;
             nx.ox = qa.x; nx.oy = qa.y; nx.oz = qa.z; nx.dx = qb.x; nx.dy = qb.y; nx.dz = qb.z; nx.tmax = step;
         },
@@ -979,7 +1017,8 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
             uint32_t e = pl.q_idx[(size_t)L_RET * pl.cap + i];
             if (e >= pl.it->n_ext) { err |= ERR_QUEUE; e = 0; }
             const float4 *rec = rec_at(pl, cur, e);
-            const float4 r0 = rec[0], r1 = rec[1], r3 = rec[3];
+            const RecHead hd = call_head(pl, ra, cur, e);
+            const float4 r0 = hd.r0, r1 = hd.r1, r3 = hd.r3;
             slot = f2u(r0.w) & (uint32_t)SLOT_MASK;
             const uint32_t ctx = f2u(r0.w) >> CTX_SHIFT;
             sid = f2u(r1.w);
@@ -1058,7 +1097,7 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
         to.finished = true; to.slot = slot;
     }
     const TailPos tp = tail_reserve(pl, cur, s_q, to, diffuse_events, counters, CNT_VISIT_RET, pending || parked, frames_read);
-    if (to.finished) pl.q_free[tp.fin] = to.slot;
+    if (to.finished) pl.q_free[cur ^ 1][tp.fin] = to.slot;
 }
 
 // ------------------------------------------------------------------------------------------ shade: fresh diffuse hits
@@ -1092,7 +1131,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         uint32_t e = pl.q_idx[(size_t)L_DIFF * pl.cap + i];
         if (e >= pl.it->n_ext) { err |= ERR_QUEUE; e = 0; }
         const float4 *rec = rec_at(pl, cur, e);
-        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        const RecHead hd = call_head(pl, ra, cur, e);
+        const float4 r0 = hd.r0, r1 = hd.r1, r2 = hd.r2, r3 = hd.r3;
         const float4 r4 = (f2u(r3.y) & FL_SHORT) ? make_float4(0, 0, 0, 0) : rec[4];
         uint32_t slot = f2u(r0.w) & (uint32_t)SLOT_MASK;
         if (slot >= pl.cap) { err |= ERR_SLOT; slot = 0; }
@@ -1190,7 +1230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         pl.q_shpath[cur ^ 1][2 * ps + 1] = make_float4(u2f(depth_trk), trk0, u2f(to.need_out), u2f(to.anc ? (uint32_t)FL_ANC : 0u));
         shp_terms = pl.q_shp_sh[cur ^ 1] + ps * (size_t)pl.nshadow;
     }
-    if (to.finished) pl.q_free[tp.fin] = to.slot;
+    if (to.finished) pl.q_free[cur ^ 1][tp.fin] = to.slot;
     if (to.need_out) {
         const int ninl = pl.rec_inline;
         flush_shadow_rays(pl, s_ray, to.need_out, tp, sh_o, sh_eo, [&](int k, float4 term) {
@@ -1288,8 +1328,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             uint32_t e = pl.q_idx[(size_t)my_list * pl.cap + my_pos];
             if (e >= pl.it->n_ext) { err |= ERR_QUEUE; e = 0; }
             const float4 *rec = rec_at(pl, cur, e);
-            qa = rec[0]; qb = rec[1];
-            const float4 r2 = rec[2], r3 = rec[3];
+            const RecHead hd = call_head(pl, ra, cur, e);
+            qa = hd.r0; qb = hd.r1;
+            const float4 r2 = hd.r2, r3 = hd.r3;
             const float4 r4 = (f2u(r3.y) & FL_SHORT) ? make_float4(0, 0, 0, 0) : rec[4];
             slot = f2u(qa.w) & (uint32_t)SLOT_MASK;
             sid = f2u(qb.w);
@@ -1661,7 +1702,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             pl.q_shpath[cur ^ 1][2 * ps + 1] = make_float4(u2f(out_depth_trk), out_trk0, u2f(need_out), u2f(anc_out ? (uint32_t)FL_ANC : 0u));
             shp_terms = pl.q_shp_sh[cur ^ 1] + ps * (size_t)pl.nshadow;
         }
-        if (finished) pl.q_free[tp.fin] = slot;
+        if (finished) pl.q_free[cur ^ 1][tp.fin] = slot;
         if (n_sray && (rec_dst || shp_terms)) {
             const int ninl = pl.rec_inline;
             flush_shadow_rays(pl, s_ray, need_out, tp, sh_o, sh_eo, [&](int k, float4 term) {
@@ -1931,7 +1972,7 @@ static uint64_t pool_bytes_per_path(int bounces, int nlights, bool curved) {
     // buffered) + extend queue (records, double buffered; class byte; index lists) + shadow-wait queue (double
     // buffered) + free list
     return 128 * nframes + 4 * (uint64_t)tracker_words(bounces) + (32 + 1 + 16 * 2) * nshadow + 16 * (uint64_t)record_quads((int)nshadow, curved) * 2 +
-           8 + 1 + 4 * NLIST + 32 * 2 + 4;
+           8 + 1 + 4 * NLIST + 32 * 2 + 4 * 2 + 32;
 }
 
 static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes, bool curved) {
@@ -1939,12 +1980,11 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes, bool
     if (rs->pool_mem && rs->pool_cap >= cap && rs->pool_bounces == bounces && rs->pool_nlights == (int)rs->nlights &&
         rs->pool_lanes >= lanes && rs->pool_curved == (int)curved)
         return PTMI_OK;                  // a larger pool of the same shape serves (tiles of different sizes)
-    if (rs->pool_mem) { (void)hipFree(rs->pool_mem); rs->pool_mem = nullptr; }
     const int nframes = bounces + 1, nshadow = (int)rs->nlights + 2;
     const int ntrk = tracker_words(bounces);
     const int rec_q = record_quads(nshadow, curved);
     const size_t c = cap;
-    struct Off { size_t fr, trk, qs0, qs1, ra, rb, occ, rec0, rec1, hit, cls, idx, ss0, ss1, free_, cnt, it; } of[RenderState::MAX_LANES];
+    struct Off { size_t fr, trk, qs0, qs1, ra, rb, occ, rec0, rec1, hit, cls, idx, ss0, ss1, free_, free1, fa, fb, cnt, it; } of[RenderState::MAX_LANES];
     size_t off = 0;
     for (int l = 0; l < lanes; ++l) {
         Off &o = of[l];
@@ -1954,14 +1994,19 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes, bool
         o.ss0 = carve(off, 16 * c * nshadow); o.ss1 = carve(off, 16 * c * nshadow);
         o.rec0 = carve(off, 16 * c * rec_q); o.rec1 = carve(off, 16 * c * rec_q);
         o.hit = carve(off, 8 * c); o.cls = carve(off, c + BIN_CHUNK); o.idx = carve(off, 4 * c * NLIST);
-        o.free_ = carve(off, 4 * c); o.cnt = carve(off, 8 * QC_COUNT * QC_STRIDE); o.it = carve(off, sizeof(IterArgs));
+        o.free_ = carve(off, 4 * c); o.free1 = carve(off, 4 * c); o.fa = carve(off, 16 * c); o.fb = carve(off, 16 * c); o.cnt = carve(off, 8 * QC_COUNT * QC_STRIDE); o.it = carve(off, sizeof(IterArgs));
     }
-    if (hipMalloc((void **)&rs->pool_mem, off) != hipSuccess) {
-        (void)hipGetLastError();
-        rs->pool_mem = nullptr; rs->pool_cap = 0;
-        return PTMI_ERR_OOM;
+    // the memory in place is laid out anew when it is large enough (another number of lanes or bounces, a pass under
+    // ptmi_set_profiling: no render call is in flight here); a 120 GB hipMalloc takes seconds
+    if (!rs->pool_mem || rs->pool_bytes < off) {
+        if (rs->pool_mem) { (void)hipFree(rs->pool_mem); rs->pool_mem = nullptr; rs->pool_bytes = 0; rs->pool_cap = 0; }
+        if (hipMalloc((void **)&rs->pool_mem, off) != hipSuccess) {
+            (void)hipGetLastError();
+            rs->pool_mem = nullptr; rs->pool_cap = 0;
+            return PTMI_ERR_OOM;
+        }
+        rs->pool_bytes = off;
     }
-    rs->pool_bytes = off;
     char *b = rs->pool_mem;
     for (int l = 0; l < lanes; ++l) {
         const Off &o = of[l];
@@ -1975,7 +2020,8 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes, bool
         p.q_hit = (float2 *)(b + o.hit); p.q_cls = (uint8_t *)(b + o.cls); p.q_idx = (uint32_t *)(b + o.idx);
         p.q_shpath[0] = (float4 *)(b + o.qs0); p.q_shpath[1] = (float4 *)(b + o.qs1);
         p.q_sray_a = (float4 *)(b + o.ra); p.q_sray_b = (float4 *)(b + o.rb);
-        p.q_free = (uint32_t *)(b + o.free_); p.qcnt = (unsigned long long *)(b + o.cnt);
+        p.q_free[0] = (uint32_t *)(b + o.free_); p.q_free[1] = (uint32_t *)(b + o.free1);
+        p.q_fresh_a = (float4 *)(b + o.fa); p.q_fresh_b = (float4 *)(b + o.fb); p.qcnt = (unsigned long long *)(b + o.cnt);
         p.it = (IterArgs *)(b + o.it);
         rs->pools[l] = p;
     }
@@ -2040,7 +2086,9 @@ static int enqueue_iteration_t(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc
     if (ctx->profiling) ctx->prof_iterations++;
     timed(ctx, PROF_PREPARE, s, [&] {
         hipLaunchKernelGGL(iter_prep_kernel, dim3(1), dim3(64), 0, s, pl, cur, (unsigned long long)lane_total, ctx->d_counters); });
-    timed(ctx, PROF_GENERATE, s, [&] { hipLaunchKernelGGL(generate_kernel, dim3(cap_wgs), dim3(256), 0, s, pl, ra, cur); });
+    timed(ctx, PROF_GENERATE, s, [&] {
+        if (ra.implicit_fresh) hipLaunchKernelGGL(generate_rays_kernel, dim3(cap_wgs), dim3(256), 0, s, pl, ra, cur);
+        else hipLaunchKernelGGL(generate_kernel, dim3(cap_wgs), dim3(256), 0, s, pl, ra, cur); });
     // extend
     uint32_t vote_from = VOTE_NEVER;
     if (!sc.has_bh && ra.p.max_steps == 1 && ctx->extend_vote) {
@@ -2220,6 +2268,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         ra.row_block = row_block; ra.row_period = row_period;
         ra.tile_first = d_tile_first; ra.tile_rect = d_tile_rect; ra.ntiles = ntiles;
         ra.spp_begin = spp_begin + done; ra.spp_chunk = chunk; ra.total = npix * chunk;
+        ra.implicit_fresh = (!rs->has_bh && prm->max_steps == 1 && ctx->implicit_fresh) ? 1u : 0u;
 
         // The wavefront loop.  The device sizes every iteration itself (iter_prep_kernel), so the host enqueues
         // iterations blind, a batch at a time, and looks at the queue counters once per batch -- one batch behind what
