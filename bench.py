@@ -457,7 +457,8 @@ def render_roofline(r, run_one_gpu, leg, npix, nshadow):
     triangles tested (48 B) by closest-hit and any-hit walks, query counts, queue entries shaded per kernel, frames
     read back.  Per-unit constants: extend 64 N_inner + 48 N_tri + 41 per query (32 B ray, 8 B
     answer, 1 B class); connect 64 N_inner + 48 N_tri + 33 per query; shade: 9 B per queue entry for the binning,
-    136 B per queue record read (72 for a fresh sample's one-sector record), 80 B triangle record per hit shaded, 64 B
+    136 B per queue record read (a fresh sample has no record where rays are straight single segments: 12 B, its answer
+    and its free-list entry; else its one-sector record, 72 B), 80 B triangle record per hit shaded, 64 B
     per frame read or parked by the lean kernels (128 by the general kernel), 128 B per child record, 32 B per shadow
     ray + 16 B per term, 20 B per finished sample (radiance + free list)."""
     r.set_profiling(True)
@@ -474,12 +475,13 @@ def render_roofline(r, run_one_gpu, leg, npix, nshadow):
     hits_shaded = c.shade_diff_visits + c.shade_general_visits
     entries = c.extend_entries                     # pending calls traced (== closest_queries unless a call marches in segments)
     children = max(0, entries - c.samples)
-    shade_bytes = (9 * entries + 136 * children + 72 * c.samples + 80 * hits_shaded + 64 * c.frames_read +
+    implicit = leg.get("max_steps", 1) == 1        # fresh samples without queue records (generate writes 32-byte rays for extend)
+    shade_bytes = (9 * entries + 136 * children + (12 if implicit else 72) * c.samples + 80 * hits_shaded + 64 * c.frames_read +
                    64 * c.shade_diff_visits + 128 * c.shade_general_visits + 128 * children + (32 + 16) * c.any_queries + 20 * c.samples)
     rows = {"extend": (NODE_BYTES * ci + TRI_BYTES * ct + 41 * entries, prof["extend_ms"]),
             "connect": (NODE_BYTES * c.any_inner_visits + TRI_BYTES * c.any_tri_tests + 33 * c.any_queries, prof["connect_ms"]),
             "shade": (shade_bytes, prof["shade_ms"]),
-            "generate": (64 * c.samples, prof["generate_ms"]),
+            "generate": ((4 + (32 if implicit else 64)) * c.samples, prof["generate_ms"]),
             "accumulate": (12 * c.samples + 16 * npix, prof["accumulate_ms"])}
     out = {"how": "per kernel class: algorithmic bytes (instrumented kernels of this run) / time (ptmi_set_profiling events, one wavefront loop)",
            "hbm_peak": HBM_PEAK_GBS, "l1_gather_peak": L1_GATHER_PEAK_GBS}
