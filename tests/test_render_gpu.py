@@ -333,6 +333,37 @@ def test_traversal_kernel_forms_agree_bit_for_bit(monkeypatch):
         assert np.array_equal(a, frames[0][0]) and np.array_equal(c, frames[0][1])
 
 
+def test_queue_forms_agree_bit_for_bit(monkeypatch):
+    """Round 3's switches that change how the queues are kept, not what is computed: fresh samples without queue
+    records (PTMI_IMPLICIT_FRESH=0: one-sector records, the form black-hole and marching scenes always use), grids of the
+    draining iterations sized by the live paths (PTMI_SHRINK_GRIDS=0: by the pool), shade by class (PTMI_SHADE_SPLIT=0:
+    everything through the general kernel), and a pool so small that the frame takes many fills.  Same sums bit for
+    bit; a marching scene (maxSteps 4: extend moves the ray and writes it back) must not be touched by the first."""
+    from pathtrace_amd import Context
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    W, H, spp = 160, 120, 6
+    for kw in ({}, {"max_steps": 4, "step_size": 40.0}):
+        p = make_params(W, H, bounces=2, seed=21, **kw)
+        frames = []
+        for env in ({}, {"PTMI_IMPLICIT_FRESH": "0"}, {"PTMI_SHRINK_GRIDS": "0"}, {"PTMI_SHADE_SPLIT": "0", "PTMI_IMPLICIT_FRESH": "1"},
+                    {"PTMI_POOL_PATHS": "65536", "PTMI_RENDER_LANES": "1"}, {"PTMI_IMPLICIT_FRESH": "0", "PTMI_SHADE_SPLIT": "0", "PTMI_POOL_PATHS": "65536"}):
+            for var in ("PTMI_IMPLICIT_FRESH", "PTMI_SHRINK_GRIDS", "PTMI_SHADE_SPLIT", "PTMI_POOL_PATHS", "PTMI_RENDER_LANES"):
+                monkeypatch.delenv(var, raising=False)
+            for var, val in env.items():
+                monkeypatch.setenv(var, val)
+            ctx = Context(0)
+            try:
+                r = Renderer(sc, ctx=ctx)
+                fb = r.new_framebuffer(W, H)
+                r.render_tile(fb, p, sc.camera, (0, 0, W, H), spp=spp)
+                frames.append((fb.accum.copy(), fb.counts.copy()))
+            finally:
+                ctx.close()
+        assert (frames[0][1] == spp).all() and float(frames[0][0].sum()) > 0
+        for a, c in frames[1:]:
+            assert np.array_equal(a, frames[0][0]) and np.array_equal(c, frames[0][1])
+
+
 def test_checkpoint_and_resume(gpu_ctx, tmp_path):
     """A frame stopped after 6 of 10 samples, written to disk, reloaded and continued equals the frame rendered in one
     go bit for bit (checkpoint / resume, which the reference does not have)."""
