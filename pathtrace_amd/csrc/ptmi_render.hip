@@ -944,7 +944,11 @@ __device__ __forceinline__ TailPos tail_reserve(const Pool &pl, int cur, float *
     if (lane == 0) {
         unsigned long long *cs = counter_shard(counters);
         if (diffuse_events) atomicAdd(&cs[CNT_DIFFUSE], (unsigned long long)diffuse_events);
+#ifdef PTMI_PROBE_LOCALITY
+        if (nvisited && visit_counter == CNT_VISIT_RET) atomicAdd(&cs[visit_counter], (unsigned long long)nvisited);
+#else
         if (nvisited) atomicAdd(&cs[visit_counter], (unsigned long long)nvisited);
+#endif
         if (frames_read) atomicAdd(&cs[CNT_FRAMES], (unsigned long long)frames_read);
     }
     lds_barrier();
@@ -1096,6 +1100,26 @@ __global__ __launch_bounds__(256) void shade_ret_kernel(Pool pl, DevScene sc, Re
         o[0] = ret.x; o[1] = ret.y; o[2] = ret.z;
         to.finished = true; to.slot = slot;
     }
+#ifdef PTMI_PROBE_LOCALITY
+    {   // experiment build: how many 12 MB windows of the frame area do the slots of a wave fall into?
+        const bool act = pending || parked;
+        const uint32_t win = to.slot >> 15;
+        const unsigned long long m = __ballot(act);
+        uint32_t distinct = 0;
+        bool mine = act;
+        for (;;) {
+            const unsigned long long b = __ballot(mine);
+            if (!b) break;
+            const uint32_t w = (uint32_t)__shfl((int)win, __ffsll((long long)b) - 1);
+            if (mine && win == w) mine = false;
+            distinct++;
+        }
+        if ((threadIdx.x & 63) == 0 && m) {
+            atomicAdd(&counter_shard(counters)[CNT_VISIT_DIFF], 1ull);
+            atomicAdd(&counter_shard(counters)[CNT_VISIT_GEN], (unsigned long long)distinct);
+        }
+    }
+#endif
     const TailPos tp = tail_reserve(pl, cur, s_q, to, diffuse_events, counters, CNT_VISIT_RET, pending || parked, frames_read);
     if (to.finished) pl.q_free[cur ^ 1][tp.fin] = to.slot;
 }
