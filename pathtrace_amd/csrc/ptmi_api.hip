@@ -114,13 +114,14 @@ __global__ __launch_bounds__(WAVE) void connect_kernel(DevBVH bvh, const float *
     if (live) {
         const float ox = o[3 * r], oy = o[3 * r + 1], oz = o[3 * r + 2];
         const float dx = d[3 * r], dy = d[3 * r + 1], dz = d[3 * r + 2];
-        occluded[r] = any_hit<WAVE, COUNT>(bvh, smem + threadIdx.x, ox, oy, oz, dx, dy, dz, tmax[r], cnt) ? 1 : 0;
+        occluded[r] = any_hit<WAVE, COUNT, !COUNT>(bvh, smem + threadIdx.x, ox, oy, oz, dx, dy, dz, tmax[r], cnt) ? 1 : 0;
     }
     flush_counters<COUNT>(cnt, counters, CNT_ANY, live ? 1u : 0u);
 }
 
-// The any-hit batch kernel, scheduled like extend_vote_kernel.  Every ray walks its nodes in the order of
-// QuickCheckIntersection, so the work counters equal the reference walk's.
+// The any-hit batch kernel, scheduled like extend_vote_kernel.  The counting variant walks a ray's nodes in the order
+// of QuickCheckIntersection, so its work counters equal the reference walk's (test); the plain variant takes the far
+// child first (vote_inner_step_any: the occlusion bit does not depend on the order, and occluders are found sooner).
 template <int STACK, bool COUNT>
 __global__ __launch_bounds__(WAVE) void connect_vote_kernel(DevBVH bvh, const float *__restrict__ o,
                                                             const float *__restrict__ d,
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(WAVE) void connect_vote_kernel(DevBVH bvh, const fl
                                                             int refill_min, int tri_bias, uint32_t chunk_rays) {
     __shared__ uint32_t smem[STACK * WAVE];
     TravCounters cnt;
-    const uint32_t nrays = vote_walk<WAVE, true, COUNT, uint64_t>(
+    const uint32_t nrays = vote_walk<WAVE, true, COUNT, uint64_t, false, !COUNT>(
         bvh, smem + threadIdx.x, n, cursor, refill_min, tri_bias, chunk_rays, cnt,
         [&](uint64_t idx, NextRay &nx, uint64_t &tag) {
             tag = idx;

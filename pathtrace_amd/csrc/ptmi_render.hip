@@ -660,7 +660,7 @@ __global__ __launch_bounds__(WAVE) void render_connect_kernel(DevBVH bvh, Pool p
         if (j >= n) continue;
         const size_t e = sray_entry(pl, sn, j);
         const float4 a = pl.q_sray_a[e], bb = pl.q_sray_b[e];
-        pl.q_sray_occ[e] = any_hit<WAVE, COUNT>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc) ? 1 : 0;
+        pl.q_sray_occ[e] = any_hit<WAVE, COUNT, true>(bvh, smem + threadIdx.x, a.x, a.y, a.z, bb.x, bb.y, bb.z, a.w, tc) ? 1 : 0;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
     flush_walk_counters<COUNT, true>(tc, counters);
@@ -676,17 +676,37 @@ __global__ __launch_bounds__(WAVE) void render_connect_vote_kernel(DevBVH bvh, P
     const uint64_t n = sray_total(sn);
     if (n < vote_from || (uint64_t)blockIdx.x * WAVE >= n) return;
     TravCounters cnt;
-    // (Tried: a per-lane cache of the last occluding triangle, tested before the walk -- the answer cannot depend on which
-    // occluder is found.  connect 125.2 -> 124.3 ms per C3 frame, 171.1 -> 171.0 on the 10.4 M-triangle scene: the time
-    // goes into the unoccluded rays, which have to visit every box their segment overlaps whatever the order.)
-    vote_walk<WAVE, true, COUNT, uint32_t>(
+#ifdef PTMI_PROBE_OCCLUDED
+    uint32_t occ_rays = 0, occ_inner = 0, occ_tri = 0, mark_i = 0, mark_t = 0;
+#endif
+    // The walk takes the far child first (vote_inner_step_any: the occlusion bit does not depend on the order); the
+    // counting variant walks in the same order, so the render leg's roofline prices the work that is done.
+    // (Tried: a per-lane cache of the last occluding triangle, tested before the walk.  connect 125.2 -> 124.3 ms per C3
+    // frame, 171.1 -> 171.0 on the 10.4 M-triangle scene: the cache rarely holds the next ray's occluder.)
+    vote_walk<WAVE, true, COUNT, uint32_t, false, true>(
         bvh, smem + threadIdx.x, n, pl.qcnt + (size_t)QC_CURSOR * QC_STRIDE, refill_min, tri_bias, vote_chunk(n, chunk_max), cnt,
         [&](uint64_t idx, NextRay &nx, uint32_t &pos) {
             const size_t e = sray_entry(pl, sn, (uint32_t)idx);
             const float4 a = pl.q_sray_a[e], bb = pl.q_sray_b[e];
             nx.ox = a.x; nx.oy = a.y; nx.oz = a.z; nx.tmax = a.w; nx.dx = bb.x; nx.dy = bb.y; nx.dz = bb.z; pos = (uint32_t)e;
         },
+#ifdef PTMI_PROBE_OCCLUDED
+        [&](uint32_t pos, const RayTrav &r) {          // experiment build: the occluded rays' share of the walk (counting variant)
+            pl.q_sray_occ[pos] = r.best ? 1 : 0;
+            if (r.best) { occ_rays++; occ_inner += cnt.inner - mark_i; occ_tri += cnt.tri - mark_t; }
+            mark_i = cnt.inner; mark_t = cnt.tri;
+        });
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) { occ_rays += __shfl_xor(occ_rays, off); occ_inner += __shfl_xor(occ_inner, off); occ_tri += __shfl_xor(occ_tri, off); }
+        if (threadIdx.x == 0) {
+            unsigned long long *cs = counter_shard(counters);
+            atomicAdd(&cs[CNT_VISIT_RET], (unsigned long long)occ_rays); atomicAdd(&cs[CNT_VISIT_DIFF], (unsigned long long)occ_inner);
+            atomicAdd(&cs[CNT_VISIT_GEN], (unsigned long long)occ_tri);
+        }
+    }
+#else
         [&](uint32_t pos, const RayTrav &r) { pl.q_sray_occ[pos] = r.best ? 1 : 0; });   // the answer goes beside the ray (one byte)
+#endif
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counter_shard(counters)[CNT_ANY], (unsigned long long)n);
     flush_walk_counters<COUNT, true>(cnt, counters);
 }
@@ -944,7 +964,9 @@ __device__ __forceinline__ TailPos tail_reserve(const Pool &pl, int cur, float *
     if (lane == 0) {
         unsigned long long *cs = counter_shard(counters);
         if (diffuse_events) atomicAdd(&cs[CNT_DIFFUSE], (unsigned long long)diffuse_events);
-#ifdef PTMI_PROBE_LOCALITY
+#if defined(PTMI_PROBE_OCCLUDED)
+        (void)nvisited;                 // the probe borrows the three visit counters
+#elif defined(PTMI_PROBE_LOCALITY)
         if (nvisited && visit_counter == CNT_VISIT_RET) atomicAdd(&cs[visit_counter], (unsigned long long)nvisited);
 #else
         if (nvisited) atomicAdd(&cs[visit_counter], (unsigned long long)nvisited);

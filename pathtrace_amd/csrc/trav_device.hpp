@@ -382,8 +382,16 @@ __device__ __forceinline__ void vote_tri_step(const DevBVH &bvh, uint32_t *stack
 // ---- any-hit forms of the two steps (QuickCheckIntersection, linear_bvh.go:202-250) -------------------
 // r.best_t holds the (constant) range, r.best becomes 1 when an occluder is found and the walk stops.
 
-// linear_bvh.go:218-246 for one inner node
-template <int BLOCK, bool COUNT, bool EXACT>
+// linear_bvh.go:218-246 for one inner node.  FAR: when the segment enters both children, take the FAR one first.  The
+// occlusion bit cannot depend on the order (the range is constant and boxes are pruned one by one, :226-245), so the
+// walk is free to choose it, and shadow rays find their occluder sooner from the far end: they start ON a surface, whose
+// neighbourhood fills the near boxes and hardly ever occludes (the ray is offset from it and leaves it behind), while
+// an occluded ray walks every near box before it reaches what blocks it -- by the counters a third of C3's shadow rays
+// are occluded and make half of all node visits, 24 per ray against 11 for a free one (tools/probe_occluded.py).
+// Far first: connect -11 % on C3, -10 % on the 10.4 M-triangle scene; the longer overlap first -5 / -7 %, the box that
+// holds the origin last -9 / -6 %, the smaller box first +4 / -2 %.  The reference's order stays for the batch
+// kernels' counting variant, whose counters are compared with the oracle's.
+template <int BLOCK, bool COUNT, bool EXACT, bool FAR = false>
 __device__ __forceinline__ void vote_inner_step_any(const DevBVH &bvh, uint32_t *stack_base, RayTrav &r, TravCounters &cnt) {
     if (COUNT) cnt.inner++;
     const float4 *p = bvh.nodes + (size_t)r.cur * 4;
@@ -399,9 +407,9 @@ __device__ __forceinline__ void vote_inner_step_any(const DevBVH &bvh, uint32_t 
     const uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
     const bool h1 = d1 < step, h2 = d2 < step;
     if (h1 && h2) {                                                 // :226-238 far child pushed first, near on top
-        const bool first_near = d1 < d2;
-        stack_base[r.sp * BLOCK] = first_near ? r1 : r0; ++r.sp;
-        r.cur = first_near ? r0 : r1;
+        const bool first0 = FAR ? !(d1 < d2) : d1 < d2;
+        stack_base[r.sp * BLOCK] = first0 ? r1 : r0; ++r.sp;
+        r.cur = first0 ? r0 : r1;
     } else if (h1 || h2) {                                          // :239-244
         r.cur = h1 ? r0 : r1;
     } else {
@@ -457,7 +465,7 @@ __device__ __forceinline__ void vote_tri_step_any(const DevBVH &bvh, uint32_t *s
 // Returns the number of rays this lane walked.  The workgroup is one wave.
 struct NextRay { float ox, oy, oz, dx, dy, dz, tmax; };
 
-template <int BLOCK, bool ANY, bool COUNT, typename Tag, bool AUX = false, typename Fetch, typename Store>
+template <int BLOCK, bool ANY, bool COUNT, typename Tag, bool AUX = false, bool FAR = false, typename Fetch, typename Store>
 __device__ __forceinline__ uint32_t vote_walk(const DevBVH &bvh, uint32_t *stack_base, uint64_t n, unsigned long long *cursor,
                                               int refill_min, int tri_bias, uint32_t chunk_rays, TravCounters &cnt,
                                               Fetch fetch, Store store) {
@@ -521,9 +529,9 @@ __device__ __forceinline__ uint32_t vote_walk(const DevBVH &bvh, uint32_t *stack
         }
         if (nI > 0 && (nT == 0 || nI + tri_bias >= nT)) {
             if (__any(at_inner && r.exact)) {
-                if (at_inner) { if (ANY) vote_inner_step_any<BLOCK, COUNT, true>(bvh, stack_base, r, cnt); else vote_inner_step<BLOCK, COUNT, true>(bvh, stack_base, r, cnt); }
+                if (at_inner) { if (ANY) vote_inner_step_any<BLOCK, COUNT, true, FAR>(bvh, stack_base, r, cnt); else vote_inner_step<BLOCK, COUNT, true>(bvh, stack_base, r, cnt); }
             } else {
-                if (at_inner) { if (ANY) vote_inner_step_any<BLOCK, COUNT, false>(bvh, stack_base, r, cnt); else vote_inner_step<BLOCK, COUNT, false>(bvh, stack_base, r, cnt); }
+                if (at_inner) { if (ANY) vote_inner_step_any<BLOCK, COUNT, false, FAR>(bvh, stack_base, r, cnt); else vote_inner_step<BLOCK, COUNT, false>(bvh, stack_base, r, cnt); }
             }
         } else {
             if (at_tri) { if (ANY) vote_tri_step_any<BLOCK, COUNT>(bvh, stack_base, r, cnt); else vote_tri_step<BLOCK, COUNT, AUX>(bvh, stack_base, r, cnt); }
@@ -532,8 +540,8 @@ __device__ __forceinline__ uint32_t vote_walk(const DevBVH &bvh, uint32_t *stack
     return nrays;
 }
 
-// QuickCheckIntersection (linear_bvh.go:202-250)
-template <int BLOCK, bool COUNT, bool EXACT>
+// QuickCheckIntersection (linear_bvh.go:202-250); FAR as in vote_inner_step_any
+template <int BLOCK, bool COUNT, bool EXACT, bool FAR>
 __device__ __forceinline__ bool any_hit_impl(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
                                              float dx, float dy, float dz, float ix, float iy, float iz, float step,
                                              TravCounters &cnt) {
@@ -550,7 +558,7 @@ __device__ __forceinline__ bool any_hit_impl(const DevBVH &bvh, uint32_t *stack_
             uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
             bool h1 = d1 < step, h2 = d2 < step;
             if (h1 && h2) {                              // :226-238 push far first, near on top
-                if (d1 < d2) { st.push(r1); cur = r0; } else { st.push(r0); cur = r1; }
+                if (FAR ? !(d1 < d2) : d1 < d2) { st.push(r1); cur = r0; } else { st.push(r0); cur = r1; }
             } else if (h1) cur = r0;                     // :239-241
             else if (h2) cur = r1;                       // :242-244
             else cur = st.empty() ? D_REF_DONE : st.pop();
@@ -583,7 +591,7 @@ __device__ __forceinline__ bool any_hit_impl(const DevBVH &bvh, uint32_t *stack_
             uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
             bool h1 = d1 < step, h2 = d2 < step;
             if (h1 && h2) {                              // :226-238 push far first, near on top
-                if (d1 < d2) { st.push(r1); cur = r0; } else { st.push(r0); cur = r1; }
+                if (FAR ? !(d1 < d2) : d1 < d2) { st.push(r1); cur = r0; } else { st.push(r0); cur = r1; }
                 continue;
             } else if (h1) { cur = r0; continue; }       // :239-241
             else if (h2) { cur = r1; continue; }         // :242-244
@@ -610,13 +618,13 @@ __device__ __forceinline__ bool any_hit_impl(const DevBVH &bvh, uint32_t *stack_
     }
 #endif
 }
-template <int BLOCK, bool COUNT>
+template <int BLOCK, bool COUNT, bool FAR = false>
 __device__ __forceinline__ bool any_hit(const DevBVH &bvh, uint32_t *stack_base, float ox, float oy, float oz,
                                         float dx, float dy, float dz, float step, TravCounters &cnt) {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     if (__any(ray_needs_exact(bvh, ox, oy, oz, ix, iy, iz, step)))
-        return any_hit_impl<BLOCK, COUNT, true>(bvh, stack_base, ox, oy, oz, dx, dy, dz, ix, iy, iz, step, cnt);
-    return any_hit_impl<BLOCK, COUNT, false>(bvh, stack_base, ox, oy, oz, dx, dy, dz, ix, iy, iz, step, cnt);
+        return any_hit_impl<BLOCK, COUNT, true, FAR>(bvh, stack_base, ox, oy, oz, dx, dy, dz, ix, iy, iz, step, cnt);
+    return any_hit_impl<BLOCK, COUNT, false, FAR>(bvh, stack_base, ox, oy, oz, dx, dy, dz, ix, iy, iz, step, cnt);
 }
 
 }  // namespace ptmi
