@@ -2046,12 +2046,13 @@ static int ensure_pool(ptmi_ctx *ctx, uint32_t cap, int bounces, int lanes, bool
     // ptmi_set_profiling: no render call is in flight here); a 120 GB hipMalloc takes seconds
     if (!rs->pool_mem || rs->pool_bytes < off) {
         if (rs->pool_mem) { (void)hipFree(rs->pool_mem); rs->pool_mem = nullptr; rs->pool_bytes = 0; rs->pool_cap = 0; }
-        if (hipMalloc((void **)&rs->pool_mem, off) != hipSuccess) {
+        const size_t want = (off + (4u << 20)) >> 20 << 20;      // slack: the lanes' fixed blocks and alignment differ by a few KB between layouts
+        if (hipMalloc((void **)&rs->pool_mem, want) != hipSuccess) {
             (void)hipGetLastError();
             rs->pool_mem = nullptr; rs->pool_cap = 0;
             return PTMI_ERR_OOM;
         }
-        rs->pool_bytes = off;
+        rs->pool_bytes = want;
     }
     char *b = rs->pool_mem;
     for (int l = 0; l < lanes; ++l) {
@@ -2249,7 +2250,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     const bool curved = rs->has_bh != 0;
     const uint64_t path_bytes = pool_bytes_per_path(bounces, (int)rs->nlights, curved);
     const uint64_t by_targets = 0xFFFFFFFFull / ((uint64_t)(bounces + 1) * (rs->nlights + 2));   // shadow-ray queue positions are 32-bit
-    const uint64_t by_budget = std::min(by_targets, std::max<uint64_t>(1u << 12, (ctx->pool_bytes_max - (1u << 20)) / path_bytes));   // 1 MiB: counters, alignment
+    const uint64_t by_budget = std::min(by_targets, std::max<uint64_t>(1u << 12, (ctx->pool_bytes_max - (5u << 20)) / path_bytes));   // 5 MiB: counters, alignment, slack
     // Two independent loops ("lanes"), each on half of the pool and of the samples and on a stream of its own, when
     // there is work for both: shade waits on memory most of the time while extend and connect keep the VALUs busy, so
     // one lane's traversal kernels fill the tails of the other's shade.  Measured on one box with the 128 M-path pool
@@ -2258,7 +2259,9 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     const int want_lanes = ctx->render_lanes < 0 ? 2 : ctx->render_lanes;
     const int lanes = (want_lanes >= 2 && max_total >= (1ull << 22) && !ctx->profiling) ? std::min(want_lanes, (int)RenderState::MAX_LANES) : 1;
     // what the work asks for, rounded up; what the limits allow, rounded down (ptmi_set_pool_limit's are ceilings)
-    const uint64_t cap_limit = std::max<uint64_t>(256, std::min<uint64_t>((uint64_t)ctx->pool_paths, by_budget) / lanes / 256 * 256);
+    // (the limit in whole blocks of 3 072 paths, so that the pool holds the same number of paths with 1, 2, 3 or 4 lanes and
+    // a pass under ptmi_set_profiling -- one lane -- fits the memory the two-lane passes before it allocated)
+    const uint64_t cap_limit = std::max<uint64_t>(256, std::min<uint64_t>((uint64_t)ctx->pool_paths, by_budget) / 3072 * 3072 / lanes);
     uint32_t cap = (uint32_t)std::min<uint64_t>(((max_total + lanes - 1) / lanes + 255) / 256 * 256, cap_limit);
     // the per-sample output buffer is in place (above); now as large a pool as fits
     int rc;
