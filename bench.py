@@ -430,7 +430,7 @@ def cpu_tile_renderer_baseline(args, dev):
 RENDER_LEGS = {
     "render": dict(scene="c3", width=1920, height=1080, spp=256, bounces=2, mode="rows",
                    workload="C3: blob + glass spheres + emissive quad + mirror sphere, gradient sky + sun (BASELINE.json configs[2])"),
-    "render_bounces4": dict(scene="c3", width=1920, height=1080, spp=64, bounces=4, mode="rows",
+    "render_bounces4": dict(scene="c3", width=1920, height=1080, spp=256, bounces=4, mode="rows",
                             workload="C3 with bounces = 4 (SURVEY 8(d): 'bounces = 2, also report 4')"),
     "render_c4": dict(scene="c4", width=3840, height=2160, spp=32, bounces=2, mode="tile",
                       workload="C4: 10.4 M-triangle scene (blob over a height field, glass, mirror, emissive quad), 4K, 64x64 tiles dealt "
