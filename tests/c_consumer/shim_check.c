@@ -121,6 +121,17 @@ static void gpu_checks(void) {
         CHECK(ptmi_render(ctx, &cam, &prm, 0, 0, 8, 8, 4, 2, accum, counts) == PTMI_OK);
         CHECK(counts[0] == 6 && counts[63] == 6);
         CHECK(ptmi_render(ctx, &cam, &prm, 4, 4, 8, 8, 0, 1, accum, counts) == PTMI_ERR_INVALID);   /* outside the image */
+        {   /* the path pool: in place after a render, given back when the limit drops under it, same sums afterwards */
+            uint64_t paths = 0, bytes = 0;
+            float accum2[64 * 3] = {0};
+            uint32_t counts2[64] = {0};
+            CHECK(ptmi_pool_info(ctx, &paths, &bytes) == PTMI_OK && paths >= 64 && bytes > 0);
+            CHECK(ptmi_set_pool_limit(NULL, 0, 0) == PTMI_ERR_INVALID);
+            CHECK(ptmi_set_pool_limit(ctx, 1, 1) == PTMI_OK);                 /* clamped to the smallest pool */
+            CHECK(ptmi_pool_info(ctx, &paths, &bytes) == PTMI_OK);
+            CHECK(ptmi_render(ctx, &cam, &prm, 0, 0, 8, 8, 0, 6, accum2, counts2) == PTMI_OK);
+            CHECK(counts2[0] == 6 && memcmp(accum, accum2, sizeof accum2) == 0);
+        }
     }
     ptmi_destroy(ctx);
 }
