@@ -2256,7 +2256,9 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
     // one lane's traversal kernels fill the tails of the other's shade.  Measured on one box with the 128 M-path pool
     // (C3, 256 spp: 1633 / 1712 / 1701 / 1637 Msamples/s with 1 / 2 / 3 / 4 lanes; the 672 MB tree at 4K: 853 / 865 /
     // 870), so two lanes by default (render_lanes < 0) whatever the tree.  The image does not depend on the split.
-    const int want_lanes = ctx->render_lanes < 0 ? 2 : ctx->render_lanes;
+    // (with the round's final kernels: C3 at 256 spp 1 846 / 1 877 / 1 731 Msamples/s with 2 / 3 / 4 lanes, the C4-class frame
+    // 932 / 939 / 856, C3 at 32 spp 1 508 / 1 490 / 1 368: three lanes for passes of 192 M samples and more)
+    const int want_lanes = ctx->render_lanes < 0 ? (max_total >= (192ull << 20) ? 3 : 2) : ctx->render_lanes;
     const int lanes = (want_lanes >= 2 && max_total >= (1ull << 22) && !ctx->profiling) ? std::min(want_lanes, (int)RenderState::MAX_LANES) : 1;
     // what the work asks for, rounded up; what the limits allow, rounded down (ptmi_set_pool_limit's are ceilings)
     // (the limit in whole blocks of 3 072 paths, so that the pool holds the same number of paths with 1, 2, 3 or 4 lanes and
