@@ -81,7 +81,7 @@ struct ptmi_ctx {
     int chunk_msamples = 1024;          // samples per pass over the region, in 2^20 (bounds the per-sample output buffer: 12 B each)
     int extend_vote = 1;                // extend (straight rays, one segment per call) as a vote-scheduled persistent kernel (0: one-shot)
     long long render_vote_min = -1;     // fewest rays a vote-scheduled launch of the integrator takes (-1: four times three chunks per resident wave, about 5 M)
-    int render_vote_chunk = 256;        // queue entries reserved per cursor atomic in the integrator's vote-scheduled kernels
+    int render_vote_chunk = 512;        // queue entries reserved per cursor atomic in the integrator's vote-scheduled kernels
     int render_vote_refill_min = 32;    // ... and idle lanes that trigger a refill there (the batch kernels: vote_refill_min)
     int segment_shortcut = 1;           // the curved march skips the walk for segments far outside the tree's tight box
     int connect_vote = 1;               // connect as a vote-scheduled persistent kernel (0: one-shot waves always)
