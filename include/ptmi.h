@@ -264,6 +264,17 @@ int ptmi_render_rows_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *
 int ptmi_render_tiles_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t ntiles,
                           const int32_t *tiles_xywh, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
                           uint32_t *counts, void *stream);
+/* Several frames of one scene in ONE call -- the orbit of the reference's frame loop (main.go:903-937: when all tile
+ * workers are done save orbit/frame<j>.png, theta += 1 degree, `scene.Camera.SphericalAround(Vec3{}, 1500, theta, phi)`
+ * (camera.go:17), start the workers again), nframes cameras at a time: frame f is rendered through
+ * cameras[f] (host array, borrowed for the call) into accum_rgb[f][height][width][3] / counts[f][height][width] (device,
+ * contiguous), samples [spp_begin, spp_begin + spp_count) of every pixel added in sample order.  The sums of frame f are
+ * those of ptmi_render_dev with cameras[f] into its slice, bit for bit.  What the call buys: a call ends by draining its
+ * path pool (iterations on fewer and fewer paths, a third of a 1080p frame at 32 spp); here the samples of the next
+ * frames fill the pool while the first ones drain, so the drain is paid once per call instead of once per frame.
+ * width x height x nframes x 3 must stay below 2^32. */
+int ptmi_render_frames_dev(ptmi_ctx *ctx, const PtCamera *cameras, uint32_t nframes, const PtParams *params, uint32_t spp_begin,
+                           uint32_t spp_count, float *accum_rgb, uint32_t *counts, void *stream);
 /* Per-sample radiance without accumulation: out[(pixel*spp_count + s)*3], host buffer. */
 int ptmi_render_samples(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, int32_t x0, int32_t y0,
                         int32_t w, int32_t h, uint32_t spp_begin, uint32_t spp_count, float *out_rgb);

@@ -176,6 +176,9 @@ struct RenderArgs {
     // and shade makes up the record of entry gen_base + j on the spot (fresh_head).  Set for straight single-segment
     // rays (extend never moves such a ray, so it has nothing to write back into the record).
     uint32_t implicit_fresh;
+    // several frames in one call (ptmi_render_frames_dev): the region is `frame_h` rows per frame, one frame under the
+    // other, and frame f is seen through cams[f] (device memory); nullptr: one frame, `cam`
+    const PtCamera *cams; int frame_h;
 };
 enum { LANE_BLOCK_LOG2 = 16, LANE_BLOCK = 1 << LANE_BLOCK_LOG2 };
 __host__ __device__ inline uint64_t lane_sample_id(uint64_t j, uint32_t lane, uint32_t nlanes) {
@@ -390,12 +393,19 @@ __device__ __forceinline__ RecHead fresh_head(const Pool &pl, const RenderArgs &
     const uint32_t pix = sid / ra.spp_chunk, smp = sid % ra.spp_chunk;
     int X, Y;
     region_pixel(ra, pix, X, Y);
+    V3 pos = mk(ra.cam.position), fwd = mk(ra.cam.forward), right = mk(ra.cam.right), up = mk(ra.cam.up);
+    float frustum = ra.cam.frustum_distance;
+    if (ra.cams) {                                  // the frame this row belongs to, and its camera
+        const int f = Y / ra.frame_h;
+        Y -= f * ra.frame_h;
+        const PtCamera *c = ra.cams + f;
+        pos = mk(c->position); fwd = mk(c->forward); right = mk(c->right); up = mk(c->up); frustum = c->frustum_distance;
+    }
     Rng rng = rng_init(ra.p.seed, (uint32_t)(Y * ra.p.width + X), ra.spp_begin + smp);
     const float rx = ((float)X + rng_f32(rng)) / (float)ra.p.width;
     const float ry = ((float)Y + rng_f32(rng)) / (float)ra.p.height;
     const float px = (rx - 0.5f) * 2.0f, py = (ry - 0.5f) * 2.0f;
-    const V3 pos = mk(ra.cam.position), fwd = mk(ra.cam.forward), right = mk(ra.cam.right), up = mk(ra.cam.up);
-    const V3 rayOrigin = add(add(add(pos, scale(fwd, ra.cam.frustum_distance)), scale(up, py)), scale(right, px));
+    const V3 rayOrigin = add(add(add(pos, scale(fwd, frustum)), scale(up, py)), scale(right, px));
     const V3 d = normalize(mk(rayOrigin.x - pos.x, rayOrigin.y - pos.y, rayOrigin.z - pos.z));
     RecHead h;
     h.r0 = make_float4(pos.x, pos.y, pos.z, u2f(slot | call_ctx(ra.p.bounces, 0, 1.0f, 0u) << CTX_SHIFT));
@@ -1838,6 +1848,7 @@ struct RenderState {
     hipEvent_t ev_qc[MAX_LANES][QC_RING] = {};
     float *d_out = nullptr; size_t out_bytes = 0;
     char *d_tiles = nullptr; size_t tiles_bytes = 0;   // tile list of ptmi_render_tiles_dev
+    PtCamera *d_cams = nullptr; size_t cams_n = 0;     // cameras of ptmi_render_frames_dev
     float *d_accum = nullptr; uint32_t *d_counts = nullptr; size_t accum_pix = 0;
 };
 
@@ -1855,7 +1866,7 @@ void free_scene(ptmi_ctx *ctx) {
     RenderState *rs = ctx->render;
     if (!rs) return;
     void *ptrs[] = {rs->d_uvs, rs->d_tex, rs->d_tex_pixels, rs->d_stri, rs->d_tri_class, rs->d_mats, rs->d_emissive, rs->d_lights,
-                    rs->d_sky_img, rs->pool_mem, rs->d_out, rs->d_accum, rs->d_counts, rs->d_tiles};
+                    rs->d_sky_img, rs->pool_mem, rs->d_out, rs->d_accum, rs->d_counts, rs->d_tiles, rs->d_cams};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &lane : rs->ev_qc) for (hipEvent_t e : lane) if (e) (void)hipEventDestroy(e);
     if (rs->ev_fork) (void)hipEventDestroy(rs->ev_fork);
@@ -2205,14 +2216,14 @@ static int enqueue_iteration(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, 
 static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, int x0, int y0, int w, int h,
                        uint32_t spp_begin, uint32_t spp_count, float *d_accum, uint32_t *d_counts, float *out_samples_host,
                        hipStream_t s, int row_block = 0, int row_period = 0, const uint32_t *d_tile_first = nullptr,
-                       const int4 *d_tile_rect = nullptr, uint32_t ntiles = 0) {
+                       const int4 *d_tile_rect = nullptr, uint32_t ntiles = 0, const PtCamera *d_cams = nullptr, int frame_h = 0) {
     RenderState *rs = ctx->render;
     if (!rs || !rs->have_scene) return set_err(ctx, PTMI_ERR_NO_SCENE, "ptmi_render: no scene uploaded");
     if (!cam || !prm) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: null camera / params");
     // a tile list: (x0, y0, w, h) = (0, 0, region pixels, 1), validated by the caller
     const bool rows_mode = row_block > 0 || ntiles > 0;
     if (w <= 0 || h <= 0 || prm->width <= 0 || prm->height <= 0 || x0 < 0 || y0 < 0 || (!ntiles && x0 + w > prm->width) ||
-        (!rows_mode && y0 + h > prm->height))
+        (!rows_mode && !d_cams && y0 + h > prm->height))
         return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: rectangle outside the image");
     if (!rows_mode || ntiles) { row_block = h; row_period = h; }
     else if (y0 + ((h - 1) / row_block) * row_period + (h - 1) % row_block >= prm->height)
@@ -2318,6 +2329,7 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
         ra.cam = *cam; ra.p = *prm; ra.x0 = x0; ra.y0 = y0; ra.w = w; ra.h = h;
         ra.row_block = row_block; ra.row_period = row_period;
         ra.tile_first = d_tile_first; ra.tile_rect = d_tile_rect; ra.ntiles = ntiles;
+        ra.cams = d_cams; ra.frame_h = frame_h;
         ra.spp_begin = spp_begin + done; ra.spp_chunk = chunk; ra.total = npix * chunk;
         ra.implicit_fresh = (!rs->has_bh && prm->max_steps == 1 && ctx->implicit_fresh) ? 1u : 0u;
 
@@ -2511,6 +2523,34 @@ extern "C" int ptmi_render_tiles_dev(ptmi_ctx *ctx, const PtCamera *camera, cons
     if (total > 0x7FFFFFFFull) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_tiles_dev: too many pixels");
     int rc = render_core(ctx, camera, params, 0, 0, (int)total, 1, spp_begin, spp_count, accum_rgb, counts, nullptr, s, 0, 0,
                          (const uint32_t *)rs->d_tiles, (const int4 *)(rs->d_tiles + b_first), ntiles);
+    if (rc) return rc;
+    PTMI_HIP(ctx, hipStreamSynchronize(s));
+    return PTMI_OK;
+}
+
+extern "C" int ptmi_render_frames_dev(ptmi_ctx *ctx, const PtCamera *cameras, uint32_t nframes, const PtParams *params, uint32_t spp_begin,
+                                      uint32_t spp_count, float *accum_rgb, uint32_t *counts, void *stream) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_render_frames_dev: ctx is null");
+    if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_render_frames_dev: no BVH");
+    RenderState *rs = ctx->render;
+    if (!rs || !rs->have_scene) return set_err(ctx, PTMI_ERR_NO_SCENE, "ptmi_render_frames_dev: no scene uploaded");
+    if (!accum_rgb || !counts || !params || (nframes && !cameras)) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_frames_dev: null argument");
+    if (nframes == 0) return PTMI_OK;
+    if (params->width <= 0 || params->height <= 0) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_frames_dev: empty image");
+    if ((uint64_t)params->height * nframes > 0x7FFFFFFFull || (uint64_t)params->width * params->height * nframes * 3 >= 0xFFFFFFFFull)
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_frames_dev: too many pixels in one call (width x height x frames x 3 < 2^32)");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    if (rs->cams_n < nframes) {
+        if (rs->d_cams) { (void)hipFree(rs->d_cams); rs->d_cams = nullptr; rs->cams_n = 0; }
+        PTMI_HIP(ctx, hipMalloc((void **)&rs->d_cams, (size_t)nframes * sizeof(PtCamera)));
+        rs->cams_n = nframes;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    PTMI_HIP(ctx, hipMemcpyAsync(rs->d_cams, cameras, (size_t)nframes * sizeof(PtCamera), hipMemcpyHostToDevice, s));
+    PTMI_HIP(ctx, hipStreamSynchronize(s));                 // the caller's array is borrowed for the call only
+    // the frames are handed to render_core as one region of nframes x height rows; fresh_head() maps a row to its frame
+    int rc = render_core(ctx, cameras, params, 0, 0, params->width, (int)(params->height * nframes), spp_begin, spp_count, accum_rgb, counts,
+                         nullptr, s, 0, 0, nullptr, nullptr, 0, rs->d_cams, params->height);
     if (rc) return rc;
     PTMI_HIP(ctx, hipStreamSynchronize(s));
     return PTMI_OK;

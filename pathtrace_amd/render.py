@@ -208,6 +208,18 @@ class Renderer:
         check(self._lib.ptmi_render_tiles_dev(self.ctx.handle, C.byref(cam), C.byref(params), t.shape[0], _ptr(t, C.c_int32),
                                               spp_begin, spp, accum.data_ptr(), counts.data_ptr(), s), self.ctx.handle)
 
+    def render_frames_device(self, accum, counts, params: PtParams, cameras, spp=32, spp_begin=0, stream=None):
+        """Several frames of the scene in one call (the reference's orbit, main.go:903-937, a batch of cameras at a time):
+        frame f through cameras[f], added into accum[f] / counts[f] of contiguous torch CUDA tensors [F,H,W,3] / [F,H,W].
+        The sums equal one render_device call per frame bit for bit; the pool's drain is paid once per call."""
+        cams = (PtCamera * len(cameras))(*[c if isinstance(c, PtCamera) else make_camera(c) for c in cameras])
+        n = len(cameras)
+        assert tuple(accum.shape) == (n, params.height, params.width, 3) and accum.is_contiguous()
+        assert tuple(counts.shape) == (n, params.height, params.width) and counts.is_contiguous()
+        s = C.c_void_p(stream) if stream else None
+        check(self._lib.ptmi_render_frames_dev(self.ctx.handle, cams, n, C.byref(params), spp_begin, spp, accum.data_ptr(),
+                                               counts.data_ptr(), s), self.ctx.handle)
+
     def render_samples(self, params: PtParams, camera, rect=None, spp=1, spp_begin=0):
         """Per-sample radiance [h,w,spp,3] (no accumulation) -- for fine-grained parity checks."""
         cam = camera if isinstance(camera, PtCamera) else make_camera(camera)

@@ -364,6 +364,36 @@ def test_queue_forms_agree_bit_for_bit(monkeypatch):
             assert np.array_equal(a, frames[0][0]) and np.array_equal(c, frames[0][1])
 
 
+def test_frames_in_one_call_equal_one_call_per_frame(gpu_ctx):
+    """ptmi_render_frames_dev: the orbit of the reference's frame loop (main.go:903-937), a batch of cameras per call.
+    Frame f's sums are those of one ptmi_render_dev call through camera f, bit for bit -- also when the frames continue
+    (spp_begin > 0), with a marching scene (records instead of record-less fresh samples), and with more than one lane."""
+    import torch
+    from pathtrace_amd import driver
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    dev = torch.device("cuda", 0)
+    r = Renderer(sc, ctx=gpu_ctx)
+    cam0 = sc.camera
+    radius = float(np.linalg.norm(np.asarray(cam0.position)))
+    cams = [driver.spherical_around((0.0, 0.0, 0.0), radius, (60.0 + 25.0 * k) * driver.DEG, 70.0 * driver.DEG, cam0.frustum) for k in range(3)]
+    for (W, H, spp, kw) in ((160, 120, 5, {}), (96, 64, 3, {"max_steps": 4, "step_size": 40.0}), (640, 480, 6, {})):
+        p = make_params(W, H, bounces=2, seed=17, **kw)
+        acc = torch.zeros((3, H, W, 3), dtype=torch.float32, device=dev); cnt = torch.zeros((3, H, W), dtype=torch.int32, device=dev)
+        r.render_frames_device(acc, cnt, p, cams, spp=spp)
+        r.render_frames_device(acc, cnt, p, cams, spp=2, spp_begin=spp)
+        assert bool((cnt == spp + 2).all())
+        for f, cam in enumerate(cams):
+            a1 = torch.zeros((H, W, 3), dtype=torch.float32, device=dev); c1 = torch.zeros((H, W), dtype=torch.int32, device=dev)
+            r.render_device(a1, c1, p, cam, spp=spp)
+            r.render_device(a1, c1, p, cam, spp=2, spp_begin=spp)
+            assert torch.equal(acc[f], a1) and torch.equal(cnt[f], c1), f
+        assert not torch.equal(acc[0], acc[1])                      # the cameras do differ
+    p = make_params(32, 32, bounces=2, seed=1)
+    acc = torch.zeros((1, 32, 32, 3), dtype=torch.float32, device=dev); cnt = torch.zeros((1, 32, 32), dtype=torch.int32, device=dev)
+    with pytest.raises(Exception):
+        r.render_frames_device(acc, cnt, make_params(0, 32), cams[:1], spp=1)
+
+
 def test_checkpoint_and_resume(gpu_ctx, tmp_path):
     """A frame stopped after 6 of 10 samples, written to disk, reloaded and continued equals the frame rendered in one
     go bit for bit (checkpoint / resume, which the reference does not have)."""
