@@ -676,6 +676,12 @@ def test_frame_loop_writes_frames(gpu_ctx, tmp_path):
     packed = read_image(tmp_path / "frame1.png")
     assert np.array_equal(packed & 0xFF, imgs[0][..., 0])
     assert sum("rays/s" in l for l in lines) == 32 and any(l.startswith(">>") for l in lines)
+    # the same orbit, three frames per ptmi_render_frames_dev call (two calls for five frames): byte-identical images
+    want = driver.frame_loop(r, sc, p, frames=5, spp=2, orbit=(7.0, 0.9, 1.1), log=lambda _l: None)
+    out2 = tmp_path / "batched"
+    got = driver.orbit_batched(r, sc, p, frames=5, spp=2, batch=3, out_dir=str(out2), orbit=(7.0, 0.9, 1.1), log=lines.append)
+    assert len(got) == 5 and all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert (out2 / "frame5.png").exists()
 
 
 def test_blackhole_scene(gpu_ctx):
