@@ -26,7 +26,7 @@ Prints ONE JSON line on rank 0.  Besides the contract's keys it carries
                         CheckIntersection single-threaded and on all cores of this job's CPU share, on a bounded
                         sample of the same batch; and the goroutine tile renderer (one worker thread per tile,
                         main.go:454-491, :832-899) on C1 with threadCount = 16 and = the CPU share.
-  render, render_bounces4, render_c4, render_c5
+  render, render_bounces4, render_c4, render_c5 (and render_orbit: 8 frames of C3 at 32 spp in one ptmi_render_frames_dev call)
                         samples/s of the wavefront integrator on BASELINE.json configs[2] (C3; also with bounces = 4),
                         configs[3] (C4: 10 M triangles, 4K, 64x64 tiles) and configs[4] (C5: black hole, 4K), at every N: with
                         N > 1 the frame is sharded over the ranks and reduced with RCCL through the C ABI ("comm": "rccl";
@@ -438,6 +438,9 @@ RENDER_LEGS = {
     "render_c5": dict(scene="c5", width=3840, height=2160, spp=2, bounces=2, mode="rows", max_steps=3000, step_size=1.0,
                       workload="C5: black hole Rs = 100 + accretion disk, RK4 geodesic march maxSteps = 3000, stepSize = 1, 4K "
                                "(BASELINE.json configs[4])"),
+    "render_orbit": dict(scene="c3", width=1920, height=1080, spp=32, bounces=2, mode="frames", frames=8,
+                         workload="an orbit of 8 frames of C3 at the reference's 32 samples per pixel (main.go:441-446, :903-937: "
+                                  "theta += 1 degree per frame), all of a rank's frames in one ptmi_render_frames_dev call"),
 }
 
 
@@ -584,6 +587,55 @@ def render_leg(name, args, rank, world, dist, dev, torch):
     return out
 
 
+def orbit_leg(name, args, rank, world, dist, dev, torch):
+    """Secondary figure: an orbit of frames at the reference's samples per pixel.  Frames are independent, so with N > 1
+    rank r renders frames r, r + N, ... and nothing is exchanged; `value` = all frames' samples / the slowest rank.  Beside
+    it the same frames as one call each (what the reference's loop would issue)."""
+    from pathtrace_amd import driver
+    from pathtrace_amd.render import Renderer, make_params
+    leg = dict(RENDER_LEGS[name])
+    sc = _leg_scene(leg["scene"])
+    r = Renderer(sc, device=dev.index)
+    W, H, spp, F = leg["width"], leg["height"], leg["spp"], leg["frames"]
+    p = make_params(W, H, bounces=leg["bounces"], seed=1)
+    radius = float(np.linalg.norm(np.asarray(sc.camera.position)))
+    cams = [driver.spherical_around((0.0, 0.0, 0.0), radius, (90.0 + f) * driver.DEG, 83.0 * driver.DEG, sc.camera.frustum) for f in range(F)]
+    mine = cams[rank::world]
+    acc = torch.zeros((max(len(mine), 1), H, W, 3), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((max(len(mine), 1), H, W), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn):
+        fn()                                       # warm-up at full size
+        acc.zero_(); cnt.zero_(); torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    t_batch = timed(lambda: mine and r.render_frames_device(acc[:len(mine)], cnt[:len(mine)], p, mine, spp=spp, stream=stream))
+    complete = bool((cnt[:len(mine)] == spp).all().item())
+    t_each = timed(lambda: [r.render_device(acc[f], cnt[f], p, mine[f], spp=spp, stream=stream) for f in range(len(mine))])
+    n = F * W * H * spp
+    out = {"metric": "samples/s, full multi-bounce integrator, frames of an orbit", "value": round(n / t_batch / 1e6, 2), "unit": "Msamples/s",
+           "seconds": round(t_batch, 4), "ms_per_frame": round(t_batch * 1e3 / F, 2), "comm": "single" if world == 1 else "none",
+           "one_call_per_frame": {"value": round(n / t_each / 1e6, 2), "unit": "Msamples/s", "ms_per_frame": round(t_each * 1e3 / F, 2)},
+           "config": {"workload": leg["workload"], "width": W, "height": H, "spp": spp, "bounces": leg["bounces"], "frames": F,
+                      "triangles": int(sc.tris.shape[0]),
+                      "sharding": "single GPU" if world == 1 else f"frame f on rank f % {world}, no exchange (frames are independent)"},
+           "frame_complete": complete}
+    r.ctx.close()
+    del r, acc, cnt
+    torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -603,7 +655,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU time budget of the closest-hit baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--render-timeout", type=float, default=420.0, help="N > 1: seconds after which stuck render legs are given up")
-    ap.add_argument("--render-legs", default="render,render_bounces4,render_c4,render_c5", help="comma-separated subset of the render legs")
+    ap.add_argument("--render-legs", default="render,render_bounces4,render_c4,render_c5,render_orbit", help="comma-separated subset of the render legs")
     ap.add_argument("--no-render-roofline", action="store_true", help="skip the profiled + counted frames of the render legs (N = 1)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -759,7 +811,7 @@ def main():
         if name not in RENDER_LEGS:
             raise SystemExit(f"unknown render leg {name!r}; known: {', '.join(RENDER_LEGS)}")
         try:
-            leg = render_leg(name, args, rank, world, dist, dev, torch)
+            leg = (orbit_leg if RENDER_LEGS[name]["mode"] == "frames" else render_leg)(name, args, rank, world, dist, dev, torch)
         except Exception as e:               # noqa: BLE001 -- reported in the line, the primary figure stands
             if world == 1:
                 raise
