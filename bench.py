@@ -486,7 +486,9 @@ def render_roofline(r, run_one_gpu, leg, npix, nshadow):
             "shade": (shade_bytes, prof["shade_ms"]),
             "generate": ((4 + (32 if implicit else 64)) * c.samples, prof["generate_ms"]),
             "accumulate": (12 * c.samples + 16 * npix, prof["accumulate_ms"])}
-    out = {"how": "per kernel class: algorithmic bytes (instrumented kernels of this run) / time (ptmi_set_profiling events, one wavefront loop)",
+    out = {"how": "per kernel class: algorithmic bytes (instrumented kernels of this run) / time (ptmi_set_profiling events, one wavefront loop); "
+                  "l1_gather_peak was measured for divergent gathers: coherent rays (primary rays are half of extend's) share cache lines, so a "
+                  "fraction near or above 1 says the kernel is at that unit's limit",
            "hbm_peak": HBM_PEAK_GBS, "l1_gather_peak": L1_GATHER_PEAK_GBS}
     total_b = total_ms = 0.0
     for k, (bts, ms) in rows.items():
