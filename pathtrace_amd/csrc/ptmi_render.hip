@@ -556,7 +556,7 @@ __device__ __forceinline__ uint32_t vote_chunk(uint64_t n, uint32_t chunk_max) {
 }
 struct ExtTag { uint32_t entry, ctx; };
 template <int STACK, bool COUNT>
-__global__ __launch_bounds__(WAVE) void render_extend_vote_kernel(DevBVH bvh, Pool pl, RenderArgs ra, int cur, uint32_t vote_from, unsigned long long *counters, int refill_min,
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(STACK <= 20 ? 8 : 1, 8))) void render_extend_vote_kernel(DevBVH bvh, Pool pl, RenderArgs ra, int cur, uint32_t vote_from, unsigned long long *counters, int refill_min,
                                                                   int tri_bias, uint32_t chunk_max) {
     __shared__ uint32_t smem[STACK * WAVE];
     const uint32_t n = pl.it->n_ext;
