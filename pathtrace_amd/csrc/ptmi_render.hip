@@ -510,10 +510,21 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
         int status = HS_MISS, prim = -1;
         float t = 0.0f;
         bool moved = false;
+        bool d_stale = false;                                                      // curved: d has not been normalised from st yet
         for (int step = 0; step < ra.p.max_steps; ++step) {
             ++nq;
-            // a geodesic spends most of its 3 000 segments far from any geometry: those queries are misses without a walk
-            if (CURVED && segment_outside_tree(bvh, o.x, o.y, o.z, d.x, d.y, d.z, ra.p.step_size)) { prim = -1; t = 0.0f; }
+            // a geodesic spends most of its 3 000 segments far from any geometry: those queries are misses without a walk,
+            // and for most of them the origin alone says so -- the direction is normalised (:241, an IEEE square root and
+            // three divisions) only for the steps that come near the tree, and once at the end for shade
+            bool skip = false;
+            if (CURVED) {
+                skip = point_far_from_tree(bvh, o.x, o.y, o.z, ra.p.step_size);
+                if (!skip) {
+                    if (d_stale) { d = normalize(mk(st.vx, st.vy, st.vz)); d_stale = false; }
+                    skip = segment_outside_tree(bvh, o.x, o.y, o.z, d.x, d.y, d.z, ra.p.step_size);
+                }
+            }
+            if (skip) { prim = -1; t = 0.0f; }
             else closest_hit<WAVE, COUNT>(bvh, smem + threadIdx.x, o.x, o.y, o.z, d.x, d.y, d.z, ra.p.step_size, prim, t, tc);
             if (prim >= 0) { status = HS_HIT; break; }
             moved = true;
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
                 st = rk4_step(st, ra.p.step_size, sc.bh.rs);                       // :231
                 V3 rel = mk(st.px, st.py, st.pz);
                 o = add(rel, mk(sc.bh.position));                                  // :238
-                d = normalize(mk(st.vx, st.vy, st.vz));                            // :241
+                d_stale = true;                                                    // :241, when someone needs it
                 if (dot(rel, rel) <= sc.bh.rs * sc.bh.rs) { status = HS_HORIZON; break; }   // :250-255
             }
         }
@@ -532,6 +543,7 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
         // shade reads the ray from the record: the origin of a hit (tracer.go:37 adds t to the CURRENT origin) and,
         // for a curved ray, the direction it ended with (the sky lookup of a miss, :260-263)
         if (CURVED) {
+            if (d_stale) d = normalize(mk(st.vx, st.vy, st.vz));
             rec[0] = make_float4(o.x, o.y, o.z, qa.w);
             rec[1] = make_float4(d.x, d.y, d.z, qb.w);
             ((float2 *)rec)[R_VT / 2] = make_float2(st.vt, vt0);

@@ -45,6 +45,18 @@ __device__ __forceinline__ bool segment_outside_tree(const DevBVH &bvh, float ox
     return ok && out;          // a NaN anywhere makes `ok` or `out` false: the walk runs
 }
 
+// The same answer from the origin alone: when o is outside the tight box by more than margin + step (x 1.001: a
+// normalised direction's components exceed 1 by rounding at most) on some axis, every segment of that length from o is
+// outside by more than the margin there, whatever its direction -- segment_outside_tree would say yes.  The curved
+// march asks this first and normalises the geodesic's direction only for the steps that come near the tree.
+__device__ __forceinline__ bool point_far_from_tree(const DevBVH &bvh, float ox, float oy, float oz, float step) {
+    if (!bvh.tight_valid) return false;
+    const float m = bvh.tight_margin + step * 1.001f, lim = SEG_OUTSIDE_MAX_ORIGIN - step * 1.001f;
+    const bool ok = fabsf(ox) <= lim && fabsf(oy) <= lim && fabsf(oz) <= lim && step >= 0.0f;
+    const bool out = ox > bvh.tight_max[0] + m || ox < bvh.tight_min[0] - m || oy > bvh.tight_max[1] + m || oy < bvh.tight_min[1] - m ||
+                     oz > bvh.tight_max[2] + m || oz < bvh.tight_min[2] - m;
+    return ok && out;          // a NaN anywhere makes `ok` or `out` false
+}
 
 // Packed node quarters: q0 = c0min.x c0max.x c1min.x c1max.x | q1 = same for y | q2 = same for z |
 // q3 = ref0 ref1 - -.  Child k's box is (q0[2k], q1[2k], q2[2k]) - (q0[2k+1], q1[2k+1], q2[2k+1]).
