@@ -432,9 +432,10 @@ RENDER_LEGS = {
                    workload="C3: blob + glass spheres + emissive quad + mirror sphere, gradient sky + sun (BASELINE.json configs[2])"),
     "render_bounces4": dict(scene="c3", width=1920, height=1080, spp=256, bounces=4, mode="rows",
                             workload="C3 with bounces = 4 (SURVEY 8(d): 'bounces = 2, also report 4')"),
-    "render_c4": dict(scene="c4", width=3840, height=2160, spp=32, bounces=2, mode="tile",
+    "render_c4": dict(scene="c4", width=3840, height=2160, spp=128, bounces=2, mode="tile",
                       workload="C4: 10.4 M-triangle scene (blob over a height field, glass, mirror, emissive quad), 4K, 64x64 tiles dealt "
-                               "tile_id % N, frame reduced onto rank 0 (BASELINE.json configs[3]; 32 of its 1024 spp per timed frame)"),
+                               "tile_id % N, frame reduced onto rank 0 (BASELINE.json configs[3]; 128 of its 1024 spp per timed frame: "
+                               "about the pass the library itself cuts a 1024-spp call at 4K into)"),
     "render_c5": dict(scene="c5", width=3840, height=2160, spp=2, bounces=2, mode="rows", max_steps=3000, step_size=1.0,
                       workload="C5: black hole Rs = 100 + accretion disk, RK4 geodesic march maxSteps = 3000, stepSize = 1, 4K "
                                "(BASELINE.json configs[4])"),
