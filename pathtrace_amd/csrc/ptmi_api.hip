@@ -252,7 +252,7 @@ static __device__ __align__(256) unsigned long long scratch[NOALLOC_SCRATCH_WORD
 
 // ------------------------------------------------------------------------------------ context
 
-extern "C" const char *ptmi_version(void) { return "ptmi 0.1 (gfx950)"; }
+extern "C" const char *ptmi_version(void) { return "ptmi 0.3 (gfx950)"; }
 
 extern "C" const char *ptmi_last_error(const ptmi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
