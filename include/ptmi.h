@@ -297,6 +297,13 @@ int ptmi_to_rgba(ptmi_ctx *ctx, const float *accum_rgb, const uint32_t *counts, 
 int ptmi_set_pool_limit(ptmi_ctx *ctx, uint64_t max_paths, uint64_t max_bytes);
 int ptmi_pool_info(ptmi_ctx *ctx, uint64_t *paths, uint64_t *bytes);
 
+/* No counterpart in the reference.  The geodesic march (BlackHole.go:74-110) takes one float32 square root and one
+ * reciprocal per acceleration, 12 000 of each per sample; away from the ends of the exponent range the library computes
+ * them with shorter instruction sequences than the compiler's general ones.  This call compares the two on EVERY float
+ * of the ranges the short forms are used on (0.7 G square roots, 1.0 G reciprocals; a few milliseconds) and returns the
+ * number that differ in any bit: 0 on a correct installation.  For integrators who want that shown on their hardware. */
+int ptmi_selftest_math(ptmi_ctx *ctx, uint64_t *mismatches);
+
 /* Per-kernel timing of the render calls -- the counterpart of the reference's runtime/pprof CPU profile around its
  * workers (main.go:797-822).  While enabled, every kernel launch of the wavefront loop is bracketed by a pair of HIP
  * events on its stream, a pass runs as ONE loop (so that the kernels do not overlap and their times add up to the

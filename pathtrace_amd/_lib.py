@@ -90,6 +90,7 @@ SIGNATURES = {
     "ptmi_counters": (C.c_int, [_P, C.POINTER(PtCounters)]),
     "ptmi_set_pool_limit": (C.c_int, [_P, C.c_uint64, C.c_uint64]),
     "ptmi_pool_info": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ptmi_selftest_math": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ptmi_set_profiling": (C.c_int, [_P, C.c_int]),
     "ptmi_render_profile": (C.c_int, [_P, C.POINTER(PtRenderProfile)]),
     "ptmi_upload_scene": (C.c_int, [_P, _P, _U64, _U32, _F, _P, _U64, _P, C.POINTER(C.c_uint16), _P]),

@@ -128,6 +128,13 @@ class Context:
     def handle(self):
         return self._ctx
 
+    def selftest_math(self):
+        """ptmi_selftest_math: floats on which the march's short square root / reciprocal differ from sqrtf / the
+        division, over every float of the ranges they are used on (0 on a correct installation)."""
+        n = C.c_uint64(0)
+        check(_lib.load().ptmi_selftest_math(self._ctx, C.byref(n)), self._ctx)
+        return int(n.value)
+
 
 class LinearBVH:
     """linear_bvh.go:72-75, resident on one GPU."""

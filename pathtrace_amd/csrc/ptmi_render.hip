@@ -2654,6 +2654,47 @@ extern "C" int ptmi_pool_info(ptmi_ctx *ctx, uint64_t *paths, uint64_t *bytes) {
     return PTMI_OK;
 }
 
+// ---- ptmi_selftest_math: sqrt_mid / rcp_mid (shade_device.hpp) against sqrtf / the division on every float of their ranges
+namespace {
+__global__ __launch_bounds__(256) void selftest_math_kernel(uint32_t sq_first, uint32_t sq_count, uint32_t rc_first, uint32_t rc_count,
+                                                            unsigned long long *bad) {
+    uint32_t wrong = 0;
+    const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t k = t0; k < sq_count; k += stride) {
+        const float x = u2f(sq_first + k);
+        wrong += f2u(sqrt_mid(x)) != f2u(sqrtf(x));
+    }
+    for (uint32_t k = t0; k < rc_count; k += stride) {
+        const float x = u2f(rc_first + k);
+        wrong += f2u(rcp_mid(x)) != f2u(1.0f / x);
+    }
+    for (int off = 32; off > 0; off >>= 1) wrong += __shfl_xor(wrong, off);
+    if ((threadIdx.x & 63) == 0 && wrong) atomicAdd(bad, (unsigned long long)wrong);
+}
+}  // namespace
+
+extern "C" int ptmi_selftest_math(ptmi_ctx *ctx, uint64_t *mismatches) {
+    if (!ctx || !mismatches) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_selftest_math: null argument");
+    PTMI_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long *d_bad = nullptr, h_bad = 0;
+    PTMI_HIP(ctx, hipMalloc((void **)&d_bad, sizeof(*d_bad)));
+    int rc = PTMI_OK;
+    do {
+        if (hipMemset(d_bad, 0, sizeof(*d_bad)) != hipSuccess) { rc = PTMI_ERR_HIP; break; }
+        // the square root on (MID_LO, MID_HI) and a float either side; the reciprocal on the cubes' range, (2^-60, 2^60)
+        float sq_lo = MID_LO, sq_hi = MID_HI, rc_lo = 0x1p-60f, rc_hi = 0x1p60f;
+        uint32_t a, b, c, d;
+        memcpy(&a, &sq_lo, 4); memcpy(&b, &sq_hi, 4); memcpy(&c, &rc_lo, 4); memcpy(&d, &rc_hi, 4);
+        hipLaunchKernelGGL(selftest_math_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, a, b - a + 1, c, d - c + 1, d_bad);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+            hipMemcpy(&h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost) != hipSuccess) { rc = PTMI_ERR_HIP; break; }
+    } while (false);
+    (void)hipFree(d_bad);
+    if (rc) return set_err(ctx, rc, "ptmi_selftest_math: HIP call failed");
+    *mismatches = (uint64_t)h_bad;
+    return PTMI_OK;
+}
+
 extern "C" int ptmi_set_profiling(ptmi_ctx *ctx, int enabled) {
     if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_set_profiling: ctx is null");
     PTMI_HIP(ctx, hipSetDevice(ctx->device));

@@ -170,14 +170,50 @@ __device__ __forceinline__ RayState get_initial_state(V3 position, V3 direction,
     s.pt = 0.0f; s.px = rel.x; s.py = rel.y; s.pz = rel.z; s.vx = direction.x; s.vy = direction.y; s.vz = direction.z;
     return s;
 }
+// The correctly rounded square root and reciprocal of an argument that is nowhere near the ends of the exponent range
+// (MID_LO < x < MID_HI for the root, MID_LO^1.5 .. MID_HI^1.5 for the reciprocal): the instruction sequences the
+// compiler emits for sqrtf(x) and 1.0f / x without the operand scaling for denormal results and without the fix-up of
+// zero / infinite / NaN operands, neither of which can apply in that range -- 9 and 7 VALU instructions instead of 16
+// and 11.  Equal to sqrtf / the division bit for bit on every float of the range (ptmi_selftest_math runs them all).
+constexpr float MID_LO = 0x1p-40f, MID_HI = 0x1p40f;
+#ifndef PTMI_MID_MATH
+#define PTMI_MID_MATH 1          // 0: the compiler's general sequences everywhere (A/B builds, tools/build_variant.sh)
+#endif
+__device__ __forceinline__ float sqrt_mid(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);                         // within 1 ulp
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);          // its neighbours
+    const float vp = __builtin_fmaf(-sd, s, x), vs = __builtin_fmaf(-su, s, x);
+    float r = vp <= 0.0f ? sd : s;
+    r = vs > 0.0f ? su : r;
+    return r;
+}
+__device__ __forceinline__ float rcp_mid(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = r;                                                       // 1.0f * r
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), r, q);
+}
+
 // BlackHole.go:74-110
 __device__ __forceinline__ void get_acceleration(const RayState &s, float rs, float &at, float &ax, float &ay, float &az) {
     float px = s.px, py = s.py, pz = s.pz, vx = s.vx, vy = s.vy, vz = s.vz;
     float r_sq = (px * px + py * py) + pz * pz;
-    if (r_sq <= rs * rs) { at = ax = ay = az = 0.0f; return; }
-    float r = sqrtf(r_sq);
-    float r_cubed = r_sq * r;
-    float inv_r_cubed = 1.0f / r_cubed;
+    // one unsigned compare for max(rs^2, MID_LO) < r_sq < MID_HI (r_sq is a sum of squares: its sign bit is clear, and
+    // the bit patterns of such floats order like their values; NaN and infinity lie above MID_HI)
+    const float lo = fmaxf(rs * rs, MID_LO);
+    const uint32_t span = lo < MID_HI ? __float_as_uint(MID_HI) - __float_as_uint(lo) - 1u : 0u;   // (uniform: the compiler hoists it out of the march)
+    float r, inv_r_cubed, r_cubed;
+    if (PTMI_MID_MATH && __float_as_uint(r_sq) - __float_as_uint(lo) - 1u < span) {
+        r = sqrt_mid(r_sq);
+        r_cubed = r_sq * r;
+        inv_r_cubed = rcp_mid(r_cubed);
+    } else {
+        if (r_sq <= rs * rs) { at = ax = ay = az = 0.0f; return; }
+        r = sqrtf(r_sq);
+        r_cubed = r_sq * r;
+        inv_r_cubed = 1.0f / r_cubed;
+    }
     float x_dot_v = (px * vx + py * vy) + pz * vz;
     float x_dot_v_sq = x_dot_v * x_dot_v;
     float rs_x_dot_v = rs * x_dot_v;

@@ -497,6 +497,18 @@ def test_two_lanes_equal_one(monkeypatch):
             assert torch.equal(frames[0][0], a) and torch.equal(frames[0][1], c)
 
 
+def test_march_square_root_and_reciprocal_are_exact_on_their_whole_range():
+    """BlackHole.go:88-90 (`r := math32.Sqrt(r_sq)`, `1.0 / r_cubed`): the march computes them with shorter instruction
+    sequences than the compiler's when the argument is away from the ends of the exponent range; ptmi_selftest_math
+    compares the two on every float of that range (0.7 G + 1.0 G values)."""
+    from pathtrace_amd import Context
+    ctx = Context(0)
+    try:
+        assert ctx.selftest_math() == 0
+    finally:
+        ctx.close()
+
+
 def test_pool_limit_does_not_change_the_image():
     """ptmi_set_pool_limit: a frame rendered through a 2^16-path pool (many passes over the free list) has the sums of
     the same frame rendered with the default pool, bit for bit; the pool in place respects the limit, and lowering the
