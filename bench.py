@@ -502,7 +502,7 @@ def render_roofline(r, run_one_gpu, leg, npix, nshadow):
                          queries=int(c.closest_queries), entries=int(entries))
     if leg.get("max_steps", 1) > 1:
         out["extend"]["note"] = ("a marching call makes up to max_steps segment queries, most of them answered without a walk; the kernel is "
-                                 "bound by the RK4 step's arithmetic (four IEEE sqrt + divide pairs), not by bytes")
+                                 "bound by the RK4 step's arithmetic (four accelerations, each with a correctly rounded square root and reciprocal), not by bytes")
     out["connect"].update(inner_per_query=round(c.any_inner_visits / max(1, c.any_queries), 2),
                           tri_per_query=round(c.any_tri_tests / max(1, c.any_queries), 2))
     out["shade"].update(visits=int(visits), ret_visits=int(c.shade_ret_visits), diff_visits=int(c.shade_diff_visits),
