@@ -506,7 +506,8 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
         V3 d = mk(qb.x, qb.y, qb.z);
         RayState st = {0, 0, 0, 0, 0, 0, 0, 0};
         float vt0 = 1.0f;
-        if (CURVED) { st = get_initial_state(o, d, sc.bh); vt0 = st.vt; }          // tracer.go:28-31
+        float st_r_sq = 0.0f;                                                      // state_r_sq(st): the horizon test's sum, reused by the next step
+        if (CURVED) { st = get_initial_state(o, d, sc.bh); vt0 = st.vt; st_r_sq = state_r_sq(st); }   // tracer.go:28-31
         int status = HS_MISS, prim = -1;
         float t = 0.0f;
         bool moved = false;
@@ -531,11 +532,12 @@ __global__ __launch_bounds__(WAVE) void render_extend_kernel(DevBVH bvh, Pool pl
             if (!CURVED) {
                 o = add(o, scale(d, ra.p.step_size));                              // :226-228
             } else {
-                st = rk4_step(st, ra.p.step_size, sc.bh.rs);                       // :231
+                st = rk4_step(st, st_r_sq, ra.p.step_size, sc.bh.rs);              // :231
                 V3 rel = mk(st.px, st.py, st.pz);
                 o = add(rel, mk(sc.bh.position));                                  // :238
                 d_stale = true;                                                    // :241, when someone needs it
-                if (dot(rel, rel) <= sc.bh.rs * sc.bh.rs) { status = HS_HORIZON; break; }   // :250-255
+                st_r_sq = dot(rel, rel);                                           // = state_r_sq(st), operation for operation
+                if (st_r_sq <= sc.bh.rs * sc.bh.rs) { status = HS_HORIZON; break; }   // :250-255
             }
         }
         pl.q_hit[i] = make_float2(u2f((uint32_t)status << 30 | ((uint32_t)prim & 0x3FFFFFFFu)), t);

@@ -196,9 +196,9 @@ __device__ __forceinline__ float rcp_mid(float d) {
 }
 
 // BlackHole.go:74-110
-__device__ __forceinline__ void get_acceleration(const RayState &s, float rs, float &at, float &ax, float &ay, float &az) {
+// r_sq = (px * px + py * py) + pz * pz of `s`, which the caller may already hold (the march's horizon test is that sum)
+__device__ __forceinline__ void get_acceleration(const RayState &s, float rs, float r_sq, float &at, float &ax, float &ay, float &az) {
     float px = s.px, py = s.py, pz = s.pz, vx = s.vx, vy = s.vy, vz = s.vz;
-    float r_sq = (px * px + py * py) + pz * pz;
     // one unsigned compare for max(rs^2, MID_LO) < r_sq < MID_HI (r_sq is a sum of squares: its sign bit is clear, and
     // the bit patterns of such floats order like their values; NaN and infinity lie above MID_HI)
     const float lo = fmaxf(rs * rs, MID_LO);
@@ -234,9 +234,14 @@ __device__ __forceinline__ RayState evaluate_rk4(const RayState &s, float dt, co
     return o;
 }
 // BlackHole.go:131-163
-__device__ __forceinline__ RayState rk4_step(const RayState &s, float h, float rs) {
+__device__ __forceinline__ float state_r_sq(const RayState &s) { return (s.px * s.px + s.py * s.py) + s.pz * s.pz; }   // BlackHole.go:80
+__device__ __forceinline__ void get_acceleration(const RayState &s, float rs, float &at, float &ax, float &ay, float &az) {
+    get_acceleration(s, rs, state_r_sq(s), at, ax, ay, az);
+}
+// s_r_sq = state_r_sq(s)
+__device__ __forceinline__ RayState rk4_step(const RayState &s, float s_r_sq, float h, float rs) {
     Rk4D k1, k2, k3, k4;
-    get_acceleration(s, rs, k1.at, k1.ax, k1.ay, k1.az);
+    get_acceleration(s, rs, s_r_sq, k1.at, k1.ax, k1.ay, k1.az);
     k1.vt = s.vt; k1.vx = s.vx; k1.vy = s.vy; k1.vz = s.vz;
     RayState tmp = evaluate_rk4(s, h * 0.5f, k1);
     get_acceleration(tmp, rs, k2.at, k2.ax, k2.ay, k2.az);
