@@ -820,6 +820,78 @@ double orc_render_tile_workers(const orc_scene *sc, const float *cam, const orc_
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
+/* The adaptive worker loop as the reference runs it when maxSamplesPerPixel > samplesPerPixel (main.go:837-897): pick
+ * the tile's noisiest pixel with Tile.GetNoisiestPixel (tile.go:34-66), give it samplesPerPixel samples, each through
+ * Pixel.AddSample (renderer.go:25-82: the sums, the count, and the luminance range behind Pixel.Contrast), until the
+ * picker returns nil.  Sequential over ONE tile, exactly in the reference's order.  A sample's radiance comes from
+ * `get(user, pixel, sample index)`: the pixel's SampleCount at that moment indexes the counter-based RNG,
+ * so the k-th sample a pixel ever gets is the same whenever it is taken.  Returns the number of picks. */
+typedef v3 (*pick_sample_fn)(void *user, int64_t pixel, uint32_t sample);
+static int64_t pick_loop(int64_t P, int spp, int max_samples, pick_sample_fn get, void *user, float *sums, uint32_t *counts,
+                         float *lum_minmax) {
+    int64_t picks = 0;
+    for (;;) {
+        int64_t best = -1;                                                     /* tile.go:35-36 */
+        float max_priority = -1.0f;
+        for (int64_t i = 0; i < P; ++i) {                                      /* :38 */
+            const int n = (int)counts[i];
+            if (n >= max_samples) continue;                                    /* :39-41 */
+            float priority;
+            if (n < 4) priority = 1e9f;                                        /* :45-46 */
+            else {
+                const float contrast = lum_minmax[2 * i + 1] - lum_minmax[2 * i];   /* Pixel.Contrast, renderer.go:81 */
+                if (n > 32 && contrast < 0.01f) continue;                      /* :51-53 */
+                priority = contrast / sqrtf((float)n);                         /* :56 */
+            }
+            if (best < 0 || priority > max_priority || (priority == max_priority && n < (int)counts[best])) {   /* :60 */
+                best = i; max_priority = priority;
+            }
+        }
+        if (best < 0) return picks;                                            /* main.go:849-852 */
+        ++picks;
+        for (int k = 0; k < spp; ++k) {                                        /* main.go:861 */
+            const v3 c = get(user, best, counts[best]);
+            counts[best] += 1;                                                 /* renderer.go:29 */
+            sums[3 * best] += c.x; sums[3 * best + 1] += c.y; sums[3 * best + 2] += c.z;   /* :59-61 */
+            const float lum = (0.2126f * c.x + 0.7152f * c.y) + 0.0722f * c.z;  /* :84-86 */
+            if (counts[best] == 1) { lum_minmax[2 * best] = lum; lum_minmax[2 * best + 1] = lum; }   /* :67-70 */
+            else {
+                if (lum < lum_minmax[2 * best]) lum_minmax[2 * best] = lum;     /* :72-77 */
+                if (lum > lum_minmax[2 * best + 1]) lum_minmax[2 * best + 1] = lum;
+            }
+            if ((int)counts[best] > max_samples) break;                        /* main.go:880-882 */
+        }
+    }
+}
+/* ... on given samples: samples[(pixel * S + s) * 3], S > max_samples (a pixel can end one sample over, main.go:880). */
+typedef struct { const float *samples; int64_t S; } given_samples;
+static v3 given_sample(void *user, int64_t pixel, uint32_t s) {
+    const given_samples *g = (const given_samples *)user;
+    const float *c = g->samples + 3 * (pixel * g->S + (int64_t)(s < g->S ? s : g->S - 1));
+    v3 r = { c[0], c[1], c[2] };
+    return r;
+}
+int64_t orc_pick_simulate(const float *samples, int64_t P, int64_t S, int spp, int max_samples, float *sums, uint32_t *counts,
+                          float *lum_minmax) {
+    if (S <= max_samples || spp < 1) return -1;
+    given_samples g = { samples, S };
+    return pick_loop(P, spp, max_samples, given_sample, &g, sums, counts, lum_minmax);
+}
+/* ... and on the scene itself: tile (x0, y0, w, h) of the frame, pixels in the tile's row-major order (main.go:474-482);
+ * sums / counts / lum_minmax are the TILE's own [h][w] arrays. */
+typedef struct { const orc_scene *sc; const float *cam; const orc_params *p; int x0, y0, w; orc_trace_counters cnt; } traced_samples;
+static v3 traced_sample(void *user, int64_t pixel, uint32_t s) {
+    traced_samples *t = (traced_samples *)user;
+    return sample_pixel(t->sc, t->p, t->cam, t->x0 + (int)(pixel % t->w), t->y0 + (int)(pixel / t->w), s, &t->cnt);
+}
+int64_t orc_render_tile_adaptive(const orc_scene *sc, const float *cam, const orc_params *p, int x0, int y0, int w, int h,
+                                 int spp, int max_samples, float *sums, uint32_t *counts, float *lum_minmax) {
+    if (spp < 1 || w < 1 || h < 1) return -1;
+    traced_samples t; memset(&t, 0, sizeof t);
+    t.sc = sc; t.cam = cam; t.p = p; t.x0 = x0; t.y0 = y0; t.w = w;
+    return pick_loop((int64_t)w * h, spp, max_samples, traced_sample, &t, sums, counts, lum_minmax);
+}
+
 /* Per-sample radiance (no accumulation), for debugging / fine-grained comparison: out[w*h*spp_count*3],
  * sample-major inside a pixel. */
 void orc_render_samples(const orc_scene *sc, const float *cam, const orc_params *p, int x0, int y0, int w, int h,

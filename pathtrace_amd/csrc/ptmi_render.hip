@@ -1799,14 +1799,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // frame_width = 0: accum / counts are the region's own [h][w] buffers; otherwise they are full frames of that
 // width and pixel (x, y) of the image is element y * frame_width + x.
 enum { ACC_TILE = 16, ACC_ROW = 3 * ACC_TILE + 1 };       // + 1 word: rows 49 words apart, no bank conflicts
+// STATS: also Pixel.MinLuminance / MaxLuminance (renderer.go:63-78, colorToLuminance :84-86) in lum[2 * pixel], [+ 1]: the
+// first sample a pixel ever gets (counts == 0) sets both, later ones widen the range with the reference's `<` / `>`.
+template <bool STATS>
 __global__ __launch_bounds__(256) void accumulate_kernel(const float *__restrict__ out, uint32_t npix, uint32_t spp, float *accum,
-                                                         uint32_t *counts, RenderArgs ra, int frame_width) {
+                                                         uint32_t *counts, RenderArgs ra, int frame_width, float *lum) {
     __shared__ float s_tile[256 * ACC_ROW];
     const uint32_t p0 = blockIdx.x * 256u, p = p0 + threadIdx.x;
     const uint32_t np = min(256u, npix - p0);                          // pixels of this workgroup
     const bool live = p < npix;
     size_t q = p;
     float r = 0.0f, g = 0.0f, b = 0.0f;
+    float lmin = 0.0f, lmax = 0.0f;
+    bool first = true;
     if (live) {
         if (frame_width > 0) {
             int x, y;
@@ -1814,6 +1819,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float *__restrict
             q = (size_t)y * (size_t)frame_width + (size_t)x;
         }
         r = accum[3 * q]; g = accum[3 * q + 1]; b = accum[3 * q + 2];
+        if (STATS && counts[q] != 0) { first = false; lmin = lum[2 * q]; lmax = lum[2 * q + 1]; }
     }
     const float *base = out + 3 * (size_t)p0 * spp;
     for (uint32_t s0 = 0; s0 < spp; s0 += ACC_TILE) {
@@ -1825,13 +1831,21 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float *__restrict
         __syncthreads();
         if (live) {
             const float *t = s_tile + threadIdx.x * ACC_ROW;
-            for (uint32_t s = 0; s < ns; ++s) { r += t[3 * s]; g += t[3 * s + 1]; b += t[3 * s + 2]; }
+            for (uint32_t s = 0; s < ns; ++s) {
+                r += t[3 * s]; g += t[3 * s + 1]; b += t[3 * s + 2];
+                if (STATS) {
+                    const float l = ((float)0.2126 * t[3 * s] + (float)0.7152 * t[3 * s + 1]) + (float)0.0722 * t[3 * s + 2];
+                    if (first) { lmin = lmax = l; first = false; }
+                    else { if (l < lmin) lmin = l; if (l > lmax) lmax = l; }
+                }
+            }
         }
         __syncthreads();
     }
     if (live) {
         accum[3 * q] = r; accum[3 * q + 1] = g; accum[3 * q + 2] = b;
         counts[q] += spp;
+        if (STATS && spp) { lum[2 * q] = lmin; lum[2 * q + 1] = lmax; }
     }
 }
 
@@ -2230,7 +2244,8 @@ static int enqueue_iteration(ptmi_ctx *ctx, const Pool &pl, const DevScene &sc, 
 static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, int x0, int y0, int w, int h,
                        uint32_t spp_begin, uint32_t spp_count, float *d_accum, uint32_t *d_counts, float *out_samples_host,
                        hipStream_t s, int row_block = 0, int row_period = 0, const uint32_t *d_tile_first = nullptr,
-                       const int4 *d_tile_rect = nullptr, uint32_t ntiles = 0, const PtCamera *d_cams = nullptr, int frame_h = 0) {
+                       const int4 *d_tile_rect = nullptr, uint32_t ntiles = 0, const PtCamera *d_cams = nullptr, int frame_h = 0,
+                       float *d_lum = nullptr) {
     RenderState *rs = ctx->render;
     if (!rs || !rs->have_scene) return set_err(ctx, PTMI_ERR_NO_SCENE, "ptmi_render: no scene uploaded");
     if (!cam || !prm) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render: null camera / params");
@@ -2434,8 +2449,12 @@ static int render_core(ptmi_ctx *ctx, const PtCamera *cam, const PtParams *prm, 
             PTMI_HIP(ctx, hipStreamSynchronize(s));
         } else {
             timed(ctx, PROF_ACCUMULATE, s, [&] {
-                hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rs->d_out,
-                                   (uint32_t)npix, chunk, d_accum, d_counts, ra, rows_mode ? prm->width : 0); });
+                if (d_lum)
+                    hipLaunchKernelGGL(accumulate_kernel<true>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rs->d_out,
+                                       (uint32_t)npix, chunk, d_accum, d_counts, ra, rows_mode ? prm->width : 0, d_lum);
+                else
+                    hipLaunchKernelGGL(accumulate_kernel<false>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rs->d_out,
+                                       (uint32_t)npix, chunk, d_accum, d_counts, ra, rows_mode ? prm->width : 0, (float *)nullptr); });
             PTMI_HIP(ctx, hipGetLastError());
         }
         if (ctx->profiling) {
@@ -2479,9 +2498,8 @@ extern "C" int ptmi_render_rows_dev(ptmi_ctx *ctx, const PtCamera *camera, const
     return PTMI_OK;
 }
 
-extern "C" int ptmi_render_tiles_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t ntiles,
-                                     const int32_t *tiles_xywh, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
-                                     uint32_t *counts, void *stream) {
+static int render_tiles(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t ntiles, const int32_t *tiles_xywh,
+                        uint32_t spp_begin, uint32_t spp_count, float *accum_rgb, uint32_t *counts, float *d_lum, void *stream) {
     if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_render_tiles_dev: ctx is null");
     if (!ctx->have_bvh) return set_err(ctx, PTMI_ERR_NO_BVH, "ptmi_render_tiles_dev: no BVH");
     RenderState *rs = ctx->render;
@@ -2536,10 +2554,21 @@ extern "C" int ptmi_render_tiles_dev(ptmi_ctx *ctx, const PtCamera *camera, cons
     // the region is handed to render_core as a 1-row strip of `total` pixels; region_pixel() maps them to the tiles
     if (total > 0x7FFFFFFFull) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_tiles_dev: too many pixels");
     int rc = render_core(ctx, camera, params, 0, 0, (int)total, 1, spp_begin, spp_count, accum_rgb, counts, nullptr, s, 0, 0,
-                         (const uint32_t *)rs->d_tiles, (const int4 *)(rs->d_tiles + b_first), ntiles);
+                         (const uint32_t *)rs->d_tiles, (const int4 *)(rs->d_tiles + b_first), ntiles, nullptr, 0, d_lum);
     if (rc) return rc;
     PTMI_HIP(ctx, hipStreamSynchronize(s));
     return PTMI_OK;
+}
+extern "C" int ptmi_render_tiles_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t ntiles,
+                                     const int32_t *tiles_xywh, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
+                                     uint32_t *counts, void *stream) {
+    return render_tiles(ctx, camera, params, ntiles, tiles_xywh, spp_begin, spp_count, accum_rgb, counts, nullptr, stream);
+}
+extern "C" int ptmi_render_tiles_stats_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t ntiles,
+                                           const int32_t *tiles_xywh, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
+                                           uint32_t *counts, float *lum_minmax, void *stream) {
+    if (ctx && !lum_minmax) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_tiles_stats_dev: lum_minmax is null");
+    return render_tiles(ctx, camera, params, ntiles, tiles_xywh, spp_begin, spp_count, accum_rgb, counts, lum_minmax, stream);
 }
 
 extern "C" int ptmi_render_frames_dev(ptmi_ctx *ctx, const PtCamera *cameras, uint32_t nframes, const PtParams *params, uint32_t spp_begin,

@@ -228,6 +228,7 @@ def main():
     ap.add_argument("--orbit-radius", type=float, default=0.0)
     ap.add_argument("--checkpoint", default=None, help="save the first frame's sums/counts here after every tile; continue a file found there")
     ap.add_argument("--batch-frames", type=int, default=0, help="render this many orbit frames per call (ptmi_render_frames_dev); 0 = the reference's tile loop")
+    ap.add_argument("--max-spp", type=int, default=0, help="adaptive sampling (tile.go:34-66): --spp samples at a time per pixel until it has this many or its contrast is under 0.01; writes <out>/adaptive.png and the per-pixel counts")
     a = ap.parse_args()
     if a.obj:
         from .obj import LoadObj
@@ -247,7 +248,19 @@ def main():
     orbit = None
     if a.orbit_radius > 0 or a.scene == "c5":
         orbit = (a.orbit_radius or 1500.0, 90.0 * DEG, 83.0 * DEG)      # main.go:625-631
-    if a.batch_frames > 0:
+    if a.max_spp > a.spp:
+        from . import adaptive
+        from .render import Framebuffer
+        t0 = time.time()
+        acc, cnt, _, rounds = adaptive.render_adaptive(r, p, sc.camera, samples_per_pixel=a.spp, max_samples=a.max_spp, log=print)
+        c = cnt.cpu().numpy().astype(np.uint32)
+        dt = time.time() - t0
+        print(f">> {int(c.sum())} samples in {len(rounds)} calls, {humanize(c.sum() / max(dt, 1e-9))} samples/s; "
+              f"{float(c.mean()):.1f} per pixel (min {int(c.min())}, max {int(c.max())})")
+        os.makedirs(a.out, exist_ok=True)
+        write_png(os.path.join(a.out, "adaptive.png"), r.to_rgba(Framebuffer(acc.cpu().numpy(), c)))
+        np.save(os.path.join(a.out, "adaptive_counts.npy"), c)
+    elif a.batch_frames > 0:
         orbit_batched(r, sc, p, frames=a.frames, spp=a.spp, batch=a.batch_frames, out_dir=a.out, orbit=orbit)
     else:
         frame_loop(r, sc, p, frames=a.frames, spp=a.spp, out_dir=a.out, orbit=orbit, checkpoint=a.checkpoint)

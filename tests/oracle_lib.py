@@ -182,6 +182,11 @@ def _load_trace():
     lib.orc_render_samples.restype = None
     lib.orc_render_samples.argtypes = [C.c_void_p, _F, C.POINTER(OrcParams), C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_uint32, C.c_uint32, _F, C.c_int]
+    lib.orc_pick_simulate.restype = C.c_int64
+    lib.orc_pick_simulate.argtypes = [_F, C.c_int64, C.c_int64, C.c_int, C.c_int, _F, _U32, _F]
+    lib.orc_render_tile_adaptive.restype = C.c_int64
+    lib.orc_render_tile_adaptive.argtypes = [C.c_void_p, _F, C.POINTER(OrcParams), C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, _F, _U32, _F]
     lib.orc_render_tile_workers.restype = C.c_double
     lib.orc_render_tile_workers.argtypes = [C.c_void_p, _F, C.POINTER(OrcParams), C.c_int, C.c_int, C.c_uint32, _F, _U32, _U64P]
     lib.orc_to_rgba.restype = None
@@ -258,6 +263,18 @@ class OracleScene:
             raise RuntimeError("orc_render_tile_workers: could not start the workers")
         return accum, counts, dict(closest=int(cnt[0]), any=int(cnt[1]), diffuse_events=int(cnt[2]), samples=int(cnt[3])), secs
 
+    def render_tile_adaptive(self, cam, params, rect, spp, max_samples):
+        """The reference's adaptive worker loop on one tile (main.go:837-897 + tile.go:34-66): (sums [h,w,3], counts
+        [h,w], lum [h,w,2], picks)."""
+        x0, y0, w, h = rect
+        cam = np.ascontiguousarray(cam, np.float32)
+        sums = np.zeros((h, w, 3), np.float32); counts = np.zeros((h, w), np.uint32); lum = np.zeros((h, w, 2), np.float32)
+        picks = self.lib.orc_render_tile_adaptive(self.h, _p(cam, C.c_float), C.byref(params), x0, y0, w, h, int(spp),
+                                                  int(max_samples), _p(sums, C.c_float), _p(counts, C.c_uint32), _p(lum, C.c_float))
+        if picks < 0:
+            raise RuntimeError("orc_render_tile_adaptive: bad arguments")
+        return sums, counts, lum, int(picks)
+
     def render_samples(self, cam, params, rect=None, spp_begin=0, spp_count=1, nthreads=8):
         x0, y0, w, h = rect or (0, 0, params.width, params.height)
         cam = np.ascontiguousarray(cam, np.float32)
@@ -265,6 +282,20 @@ class OracleScene:
         self.lib.orc_render_samples(self.h, _p(cam, C.c_float), C.byref(params), x0, y0, w, h, spp_begin, spp_count,
                                     _p(out, C.c_float), nthreads)
         return out
+
+
+def pick_simulate(samples, spp, max_samples):
+    """The reference's adaptive worker loop on one tile whose samples are given ([P, S, 3] float32, S > max_samples):
+    (sums [P,3], counts [P], lum [P,2], picks)."""
+    lib = _load_trace()
+    smp = np.ascontiguousarray(samples, np.float32)
+    P, S = smp.shape[0], smp.shape[1]
+    sums = np.zeros((P, 3), np.float32); counts = np.zeros(P, np.uint32); lum = np.zeros((P, 2), np.float32)
+    picks = lib.orc_pick_simulate(_p(smp, C.c_float), P, S, int(spp), int(max_samples), _p(sums, C.c_float),
+                                  _p(counts, C.c_uint32), _p(lum, C.c_float))
+    if picks < 0:
+        raise RuntimeError("orc_pick_simulate: need S > max_samples and spp >= 1")
+    return sums, counts, lum, int(picks)
 
 
 def to_rgba(accum, counts):
