@@ -12,8 +12,8 @@ parallel: round r renders the next batch of every pixel still eligible, in one `
 whose tiles are the runs of eligible pixels.  (At the reference's committed constants, samplesPerPixel ==
 maxSamplesPerPixel == 32, there is one round and every pixel gets 32 samples: SURVEY 3.2.)
 
-The reference's sequential loop itself is restated in `oracle/orc_trace.c` (`orc_pick_simulate`,
-`orc_render_tile_adaptive`); `tests/test_adaptive.py` holds the two against each other.
+The reference's sequential loop itself is restated on the CPU for the tests (`tests/test_adaptive.py` holds the two
+against each other, bit for bit).
 """
 from __future__ import annotations
 
