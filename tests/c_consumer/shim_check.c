@@ -132,6 +132,13 @@ static void gpu_checks(void) {
             CHECK(ptmi_render(ctx, &cam, &prm, 0, 0, 8, 8, 0, 6, accum2, counts2) == PTMI_OK);
             CHECK(counts2[0] == 6 && memcmp(accum, accum2, sizeof accum2) == 0);
         }
+        {   /* the march's short square root / reciprocal against the compiler's, every float of their ranges */
+            uint64_t bad = 1;
+            CHECK(ptmi_selftest_math(NULL, &bad) == PTMI_ERR_INVALID && ptmi_selftest_math(ctx, NULL) == PTMI_ERR_INVALID);
+            CHECK(ptmi_selftest_math(ctx, &bad) == PTMI_OK && bad == 0);
+        }
+        /* ptmi_render_tiles_stats_dev takes device buffers (the Python tests drive it); its argument checks from here */
+        CHECK(ptmi_render_tiles_stats_dev(ctx, &cam, &prm, 0, NULL, 0, 1, accum, counts, NULL, NULL) == PTMI_ERR_INVALID);
     }
     ptmi_destroy(ctx);
 }
