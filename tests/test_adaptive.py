@@ -135,3 +135,46 @@ def test_gpu_rounds_equal_the_sequential_picker(gpu_ctx, spp, max_samples):
     assert len(np.unique(counts)) >= 2 and counts.min() > 32           # background pixels stop early, noisy ones go on
     assert sum(n for n, _ in rounds) == counts.max()
     assert rounds[0][1] == W * H and rounds[-1][1] < W * H
+
+
+@pytest.mark.gpu
+def test_luminance_range_across_passes_and_lanes(monkeypatch):
+    """A call cut into several passes (PTMI_CHUNK_MSAMPLES=1: 1 M samples per pass) and run on two lanes keeps the sums
+    and the luminance ranges of the same call in one pass: accumulate continues a pixel's range from the pass before."""
+    import torch
+    from pathtrace_amd import Context
+    sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
+    W, H, spp = 256, 192, 72                     # 3.5 M samples
+    p = make_params(W, H, bounces=2, seed=9)
+    dev = torch.device("cuda", 0)
+    got = []
+    for env in ({}, {"PTMI_CHUNK_MSAMPLES": "1"}, {"PTMI_CHUNK_MSAMPLES": "1", "PTMI_RENDER_LANES": "1"}):
+        for var in ("PTMI_CHUNK_MSAMPLES", "PTMI_RENDER_LANES"):
+            monkeypatch.delenv(var, raising=False)
+        for var, val in env.items():
+            monkeypatch.setenv(var, val)
+        ctx = Context(0)
+        try:
+            r = Renderer(sc, ctx=ctx)
+            acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+            cnt = torch.zeros((H, W), dtype=torch.int32, device=dev)
+            lum = torch.zeros((H, W, 2), dtype=torch.float32, device=dev)
+            tiles = [(0, 0, W, H // 2), (0, H // 2, W // 2, H // 2), (W // 2, H // 2, W // 2, H // 2)]
+            r.render_tiles_device(acc, cnt, p, sc.camera, tiles, spp=spp - 8, lum=lum)
+            r.render_tiles_device(acc, cnt, p, sc.camera, tiles, spp=8, spp_begin=spp - 8, lum=lum)      # a later call continues too
+            got.append((acc.cpu().numpy(), cnt.cpu().numpy(), lum.cpu().numpy()))
+        finally:
+            ctx.close()
+    a0, c0, l0 = got[0]
+    assert (c0 == spp).all() and (l0[..., 1] >= l0[..., 0]).all() and (l0[..., 1] > l0[..., 0]).any()
+    for a, c, l in got[1:]:
+        assert np.array_equal(a.view(np.uint32), a0.view(np.uint32)) and np.array_equal(c, c0)
+        assert np.array_equal(l.view(np.uint32), l0.view(np.uint32))
+    # and the range is that of the per-sample luminances
+    ctx = Context(0)
+    try:
+        smp = Renderer(sc, ctx=ctx).render_samples(p, sc.camera, rect=(100, 60, 32, 8), spp=spp)
+    finally:
+        ctx.close()
+    lumv = (f32(0.2126) * smp[..., 0] + f32(0.7152) * smp[..., 1]) + f32(0.0722) * smp[..., 2]
+    assert np.array_equal(lumv.min(-1), l0[60:68, 100:132, 0]) and np.array_equal(lumv.max(-1), l0[60:68, 100:132, 1])
