@@ -264,18 +264,21 @@ int ptmi_render_rows_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *
 int ptmi_render_tiles_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t ntiles,
                           const int32_t *tiles_xywh, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
                           uint32_t *counts, void *stream);
-/* ptmi_render_tiles_dev that also keeps Pixel.MinLuminance / MaxLuminance (renderer.go:63-78; luminance =
- * 0.2126 R + 0.7152 G + 0.0722 B of a sample, :84-86) in lum_minmax[(y*width + x)*2 .. +1] (device, full frame): the
- * first sample a pixel ever gets (counts == 0) sets both, later ones widen the range.  Pixel.Contrast (:81) = max - min
- * is what Tile.GetNoisiestPixel (tile.go:34-66) ranks and stops pixels by.  That picker hands out samplesPerPixel
- * samples at a time to one pixel of a tile, but whether a pixel is picked AGAIN depends on that pixel alone (its count
- * against maxSamplesPerPixel, and count > 32 && contrast < 0.01, :39, :51), so the finished image is the same when every
- * pixel still eligible gets its next samplesPerPixel samples in one call per round: the host reads the contrast,
- * lists the runs of eligible pixels as 1-row tiles, and calls this again with spp_begin advanced
- * (pathtrace_amd/adaptive.py; INTEGRATION.md has the Go text). */
+/* ptmi_render_tiles_dev that also keeps the rest of Pixel.AddSample's state (renderer.go:25-82) in
+ * pixel_stats[(y*width + x)*PTMI_PIXEL_STATS + k] (device, full frame, zeroed by the caller before a pixel's first sample):
+ * k = 0, 1 MinLuminance, MaxLuminance (:63-78; luminance = 0.2126 R + 0.7152 G + 0.0722 B of a sample, :84-86; the first
+ * sample a pixel ever gets sets both, later ones widen the range), 2-4 Mean, 5-7 M2 (:33-51), 8 Variance (:53-57), every
+ * operation as the source writes it, in sample order.  Pixel.Contrast (:81) = max - min is what Tile.GetNoisiestPixel
+ * (tile.go:34-66) ranks and stops pixels by.  That picker hands out samplesPerPixel samples at a time to one pixel of a
+ * tile, but whether a pixel is picked AGAIN depends on that pixel alone (its count against maxSamplesPerPixel, and
+ * count > 32 && contrast < 0.01, :39, :51), and its contrast only grows, so the finished image takes two calls: all
+ * pixels up to the first count above 32, then the host reads the contrast, lists the runs of pixels at or above 0.01 as
+ * 1-row tiles, and calls this again for their remaining samples (pathtrace_amd/adaptive.py; INTEGRATION.md has the Go
+ * text). */
+#define PTMI_PIXEL_STATS 9
 int ptmi_render_tiles_stats_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t ntiles,
                                 const int32_t *tiles_xywh, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
-                                uint32_t *counts, float *lum_minmax, void *stream);
+                                uint32_t *counts, float *pixel_stats, void *stream);
 /* Several frames of one scene in ONE call -- the orbit of the reference's frame loop (main.go:903-937: when all tile
  * workers are done save orbit/frame<j>.png, theta += 1 degree, `scene.Camera.SphericalAround(Vec3{}, 1500, theta, phi)`
  * (camera.go:17), start the workers again), nframes cameras at a time: frame f is rendered through

@@ -822,13 +822,15 @@ double orc_render_tile_workers(const orc_scene *sc, const float *cam, const orc_
 
 /* The adaptive worker loop as the reference runs it when maxSamplesPerPixel > samplesPerPixel (main.go:837-897): pick
  * the tile's noisiest pixel with Tile.GetNoisiestPixel (tile.go:34-66), give it samplesPerPixel samples, each through
- * Pixel.AddSample (renderer.go:25-82: the sums, the count, and the luminance range behind Pixel.Contrast), until the
+ * Pixel.AddSample (renderer.go:25-82: the sums, the count, Welford's mean / M2 / variance and the luminance range behind
+ * Pixel.Contrast), until the
  * picker returns nil.  Sequential over ONE tile, exactly in the reference's order.  A sample's radiance comes from
  * `get(user, pixel, sample index)`: the pixel's SampleCount at that moment indexes the counter-based RNG,
  * so the k-th sample a pixel ever gets is the same whenever it is taken.  Returns the number of picks. */
 typedef v3 (*pick_sample_fn)(void *user, int64_t pixel, uint32_t sample);
+enum { ORC_PIXEL_STATS = 9 };          /* per pixel: MinLuminance, MaxLuminance, Mean[3], M2[3], Variance (renderer.go:12-22) */
 static int64_t pick_loop(int64_t P, int spp, int max_samples, pick_sample_fn get, void *user, float *sums, uint32_t *counts,
-                         float *lum_minmax) {
+                         float *stats) {
     int64_t picks = 0;
     for (;;) {
         int64_t best = -1;                                                     /* tile.go:35-36 */
@@ -839,7 +841,7 @@ static int64_t pick_loop(int64_t P, int spp, int max_samples, pick_sample_fn get
             float priority;
             if (n < 4) priority = 1e9f;                                        /* :45-46 */
             else {
-                const float contrast = lum_minmax[2 * i + 1] - lum_minmax[2 * i];   /* Pixel.Contrast, renderer.go:81 */
+                const float contrast = stats[ORC_PIXEL_STATS * i + 1] - stats[ORC_PIXEL_STATS * i];   /* Pixel.Contrast, renderer.go:81 */
                 if (n > 32 && contrast < 0.01f) continue;                      /* :51-53 */
                 priority = contrast / sqrtf((float)n);                         /* :56 */
             }
@@ -853,11 +855,17 @@ static int64_t pick_loop(int64_t P, int spp, int max_samples, pick_sample_fn get
             const v3 c = get(user, best, counts[best]);
             counts[best] += 1;                                                 /* renderer.go:29 */
             sums[3 * best] += c.x; sums[3 * best + 1] += c.y; sums[3 * best + 2] += c.z;   /* :59-61 */
+            float *st = stats + ORC_PIXEL_STATS * best;                         /* min, max luminance; Mean; M2; Variance */
+            const float n = (float)counts[best];                               /* :30 */
+            const float dx = c.x - st[2], dy = c.y - st[3], dz = c.z - st[4];  /* :33-37 */
+            st[2] += dx / n; st[3] += dy / n; st[4] += dz / n;                 /* :39-41 */
+            st[5] += dx * (c.x - st[2]); st[6] += dy * (c.y - st[3]); st[7] += dz * (c.z - st[4]);   /* :43-51 */
+            if (counts[best] > 1) st[8] = ((st[5] + st[6]) + st[7]) / (3.0f * (n - 1.0f));           /* :53-57 */
             const float lum = (0.2126f * c.x + 0.7152f * c.y) + 0.0722f * c.z;  /* :84-86 */
-            if (counts[best] == 1) { lum_minmax[2 * best] = lum; lum_minmax[2 * best + 1] = lum; }   /* :67-70 */
+            if (counts[best] == 1) { st[0] = lum; st[1] = lum; }               /* :67-70 */
             else {
-                if (lum < lum_minmax[2 * best]) lum_minmax[2 * best] = lum;     /* :72-77 */
-                if (lum > lum_minmax[2 * best + 1]) lum_minmax[2 * best + 1] = lum;
+                if (lum < st[0]) st[0] = lum;                                  /* :72-77 */
+                if (lum > st[1]) st[1] = lum;
             }
             if ((int)counts[best] > max_samples) break;                        /* main.go:880-882 */
         }
@@ -872,24 +880,24 @@ static v3 given_sample(void *user, int64_t pixel, uint32_t s) {
     return r;
 }
 int64_t orc_pick_simulate(const float *samples, int64_t P, int64_t S, int spp, int max_samples, float *sums, uint32_t *counts,
-                          float *lum_minmax) {
+                          float *stats) {
     if (S <= max_samples || spp < 1) return -1;
     given_samples g = { samples, S };
-    return pick_loop(P, spp, max_samples, given_sample, &g, sums, counts, lum_minmax);
+    return pick_loop(P, spp, max_samples, given_sample, &g, sums, counts, stats);
 }
 /* ... and on the scene itself: tile (x0, y0, w, h) of the frame, pixels in the tile's row-major order (main.go:474-482);
- * sums / counts / lum_minmax are the TILE's own [h][w] arrays. */
+ * sums / counts / stats are the TILE's own [h][w] arrays (stats: ORC_PIXEL_STATS floats per pixel). */
 typedef struct { const orc_scene *sc; const float *cam; const orc_params *p; int x0, y0, w; orc_trace_counters cnt; } traced_samples;
 static v3 traced_sample(void *user, int64_t pixel, uint32_t s) {
     traced_samples *t = (traced_samples *)user;
     return sample_pixel(t->sc, t->p, t->cam, t->x0 + (int)(pixel % t->w), t->y0 + (int)(pixel / t->w), s, &t->cnt);
 }
 int64_t orc_render_tile_adaptive(const orc_scene *sc, const float *cam, const orc_params *p, int x0, int y0, int w, int h,
-                                 int spp, int max_samples, float *sums, uint32_t *counts, float *lum_minmax) {
+                                 int spp, int max_samples, float *sums, uint32_t *counts, float *stats) {
     if (spp < 1 || w < 1 || h < 1) return -1;
     traced_samples t; memset(&t, 0, sizeof t);
     t.sc = sc; t.cam = cam; t.p = p; t.x0 = x0; t.y0 = y0; t.w = w;
-    return pick_loop((int64_t)w * h, spp, max_samples, traced_sample, &t, sums, counts, lum_minmax);
+    return pick_loop((int64_t)w * h, spp, max_samples, traced_sample, &t, sums, counts, stats);
 }
 
 /* Per-sample radiance (no accumulation), for debugging / fine-grained comparison: out[w*h*spp_count*3],

@@ -53,7 +53,7 @@ def pick_counts(samples_per_pixel: int, max_samples: int):
 
 def render_adaptive(renderer, params, camera, samples_per_pixel=32, max_samples=1024, device=None, log=None, merge=True):
     """Renders the frame until Tile.GetNoisiestPixel would return nil for every tile.  Returns (accum [H,W,3] f32,
-    counts [H,W] i32, lum [H,W,2] f32) as torch CUDA tensors and the list of (samples in the call, eligible pixels).
+    counts [H,W] i32, stats [H,W,9] f32: min / max luminance, Mean, M2, Variance) as torch CUDA tensors and the list of (samples in the call, eligible pixels).
 
     merge=False: one call per batch of samples_per_pixel, the eligible set re-read before each.  merge=True (same sums,
     bit for bit): TWO calls.  The contrast test (tile.go:51) first applies to a pixel holding more than 32 samples, so
@@ -65,7 +65,7 @@ def render_adaptive(renderer, params, camera, samples_per_pixel=32, max_samples=
     H, W = params.height, params.width
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     counts = torch.zeros((H, W), dtype=torch.int32, device=dev)
-    lum = torch.zeros((H, W, 2), dtype=torch.float32, device=dev)
+    lum = torch.zeros((H, W, renderer.PIXEL_STATS), dtype=torch.float32, device=dev)
     seq = pick_counts(samples_per_pixel, max_samples)
     if merge:       # the count at which the contrast test first decides anything, then the stopping count
         tested = [c for c in seq[:-1] if c > CONTRAST_FROM]
@@ -79,7 +79,7 @@ def render_adaptive(renderer, params, camera, samples_per_pixel=32, max_samples=
         if not eligible.any():
             break
         tiles = mask_runs(eligible)
-        renderer.render_tiles_device(accum, counts, params, camera, tiles, spp=target - count, spp_begin=count, lum=lum)
+        renderer.render_tiles_device(accum, counts, params, camera, tiles, spp=target - count, spp_begin=count, stats=lum)
         calls.append((target - count, int(eligible.sum())))
         if log:
             log(f"call {len(calls)}: samples {count}..{target} of {calls[-1][1]} pixels in {len(tiles)} runs")

@@ -1799,8 +1799,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // frame_width = 0: accum / counts are the region's own [h][w] buffers; otherwise they are full frames of that
 // width and pixel (x, y) of the image is element y * frame_width + x.
 enum { ACC_TILE = 16, ACC_ROW = 3 * ACC_TILE + 1 };       // + 1 word: rows 49 words apart, no bank conflicts
-// STATS: also Pixel.MinLuminance / MaxLuminance (renderer.go:63-78, colorToLuminance :84-86) in lum[2 * pixel], [+ 1]: the
-// first sample a pixel ever gets (counts == 0) sets both, later ones widen the range with the reference's `<` / `>`.
+// STATS: also the rest of Pixel.AddSample (renderer.go:25-82) in stats[PTMI_PIXEL_STATS * pixel + ..]: MinLuminance,
+// MaxLuminance (:63-78, colorToLuminance :84-86: the first sample a pixel ever gets sets both, later ones widen the range
+// with the reference's `<` / `>`), the running Mean and M2 per channel (:33-51, Welford) and Variance (:53-57), each
+// operation as the source writes it, in sample order.
 template <bool STATS>
 __global__ __launch_bounds__(256) void accumulate_kernel(const float *__restrict__ out, uint32_t npix, uint32_t spp, float *accum,
                                                          uint32_t *counts, RenderArgs ra, int frame_width, float *lum) {
@@ -1810,8 +1812,8 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float *__restrict
     const bool live = p < npix;
     size_t q = p;
     float r = 0.0f, g = 0.0f, b = 0.0f;
-    float lmin = 0.0f, lmax = 0.0f;
-    bool first = true;
+    float lmin = 0.0f, lmax = 0.0f, mr = 0.0f, mg = 0.0f, mb = 0.0f, m2r = 0.0f, m2g = 0.0f, m2b = 0.0f, var = 0.0f;
+    uint32_t have = 0;                                                 // the pixel's SampleCount
     if (live) {
         if (frame_width > 0) {
             int x, y;
@@ -1819,7 +1821,10 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float *__restrict
             q = (size_t)y * (size_t)frame_width + (size_t)x;
         }
         r = accum[3 * q]; g = accum[3 * q + 1]; b = accum[3 * q + 2];
-        if (STATS && counts[q] != 0) { first = false; lmin = lum[2 * q]; lmax = lum[2 * q + 1]; }
+        if (STATS && (have = counts[q]) != 0) {
+            const float *st = lum + (size_t)PTMI_PIXEL_STATS * q;
+            lmin = st[0]; lmax = st[1]; mr = st[2]; mg = st[3]; mb = st[4]; m2r = st[5]; m2g = st[6]; m2b = st[7]; var = st[8];
+        }
     }
     const float *base = out + 3 * (size_t)p0 * spp;
     for (uint32_t s0 = 0; s0 < spp; s0 += ACC_TILE) {
@@ -1834,9 +1839,16 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float *__restrict
             for (uint32_t s = 0; s < ns; ++s) {
                 r += t[3 * s]; g += t[3 * s + 1]; b += t[3 * s + 2];
                 if (STATS) {
-                    const float l = ((float)0.2126 * t[3 * s] + (float)0.7152 * t[3 * s + 1]) + (float)0.0722 * t[3 * s + 2];
-                    if (first) { lmin = lmax = l; first = false; }
-                    else { if (l < lmin) lmin = l; if (l > lmax) lmax = l; }
+                    const float cx = t[3 * s], cy = t[3 * s + 1], cz = t[3 * s + 2];
+                    ++have;                                                                      // :29
+                    const float n = (float)have;
+                    const float dx = cx - mr, dy = cy - mg, dz = cz - mb;                        // :33-37
+                    mr += dx / n; mg += dy / n; mb += dz / n;                                    // :39-41
+                    m2r += dx * (cx - mr); m2g += dy * (cy - mg); m2b += dz * (cz - mb);         // :43-51
+                    if (have > 1) var = ((m2r + m2g) + m2b) / (3.0f * (n - 1.0f));               // :53-57
+                    const float l = ((float)0.2126 * cx + (float)0.7152 * cy) + (float)0.0722 * cz;   // :84-86
+                    if (have == 1) { lmin = lmax = l; }                                          // :67-70
+                    else { if (l < lmin) lmin = l; if (l > lmax) lmax = l; }                     // :72-77
                 }
             }
         }
@@ -1845,7 +1857,10 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float *__restrict
     if (live) {
         accum[3 * q] = r; accum[3 * q + 1] = g; accum[3 * q + 2] = b;
         counts[q] += spp;
-        if (STATS && spp) { lum[2 * q] = lmin; lum[2 * q + 1] = lmax; }
+        if (STATS && spp) {
+            float *st = lum + (size_t)PTMI_PIXEL_STATS * q;
+            st[0] = lmin; st[1] = lmax; st[2] = mr; st[3] = mg; st[4] = mb; st[5] = m2r; st[6] = m2g; st[7] = m2b; st[8] = var;
+        }
     }
 }
 
@@ -2566,9 +2581,9 @@ extern "C" int ptmi_render_tiles_dev(ptmi_ctx *ctx, const PtCamera *camera, cons
 }
 extern "C" int ptmi_render_tiles_stats_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t ntiles,
                                            const int32_t *tiles_xywh, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
-                                           uint32_t *counts, float *lum_minmax, void *stream) {
-    if (ctx && !lum_minmax) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_tiles_stats_dev: lum_minmax is null");
-    return render_tiles(ctx, camera, params, ntiles, tiles_xywh, spp_begin, spp_count, accum_rgb, counts, lum_minmax, stream);
+                                           uint32_t *counts, float *pixel_stats, void *stream) {
+    if (ctx && !pixel_stats) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_tiles_stats_dev: pixel_stats is null");
+    return render_tiles(ctx, camera, params, ntiles, tiles_xywh, spp_begin, spp_count, accum_rgb, counts, pixel_stats, stream);
 }
 
 extern "C" int ptmi_render_frames_dev(ptmi_ctx *ctx, const PtCamera *cameras, uint32_t nframes, const PtParams *params, uint32_t spp_begin,

@@ -198,19 +198,21 @@ class Renderer:
         check(self._lib.ptmi_render_sharded(self.ctx.handle, C.byref(cam), C.byref(params), row_block, spp_begin, spp,
                                             accum.data_ptr(), counts.data_ptr(), root, s), self.ctx.handle)
 
-    def render_tiles_device(self, accum, counts, params: PtParams, camera, tiles, spp=32, spp_begin=0, stream=None, lum=None):
+    PIXEL_STATS = 9      # PTMI_PIXEL_STATS: min / max luminance, Mean[3], M2[3], Variance
+
+    def render_tiles_device(self, accum, counts, params: PtParams, camera, tiles, spp=32, spp_begin=0, stream=None, stats=None):
         """Several disjoint tiles [(x0, y0, w, h), ...] in one call, added into FULL-FRAME torch CUDA tensors.
-        lum: optional [H,W,2] float32 CUDA tensor that keeps every pixel's min / max sample luminance
-        (Pixel.MinLuminance / MaxLuminance, renderer.go:63-78; ptmi_render_tiles_stats_dev)."""
+        stats: optional [H,W,9] float32 CUDA tensor that keeps the rest of Pixel.AddSample's state per pixel (min / max
+        sample luminance, Mean, M2, Variance: renderer.go:25-82; ptmi_render_tiles_stats_dev)."""
         cam = camera if isinstance(camera, PtCamera) else make_camera(camera)
         assert tuple(accum.shape) == (params.height, params.width, 3) and accum.is_contiguous()
         assert tuple(counts.shape) == (params.height, params.width) and counts.is_contiguous()
         t = np.ascontiguousarray(np.asarray(tiles, np.int32).reshape(-1, 4))
         s = C.c_void_p(stream) if stream else None
-        if lum is not None:
-            assert tuple(lum.shape) == (params.height, params.width, 2) and lum.is_contiguous() and lum.element_size() == 4
+        if stats is not None:
+            assert tuple(stats.shape) == (params.height, params.width, self.PIXEL_STATS) and stats.is_contiguous() and stats.element_size() == 4
             check(self._lib.ptmi_render_tiles_stats_dev(self.ctx.handle, C.byref(cam), C.byref(params), t.shape[0], _ptr(t, C.c_int32),
-                                                        spp_begin, spp, accum.data_ptr(), counts.data_ptr(), lum.data_ptr(), s),
+                                                        spp_begin, spp, accum.data_ptr(), counts.data_ptr(), stats.data_ptr(), s),
                   self.ctx.handle)
             return
         check(self._lib.ptmi_render_tiles_dev(self.ctx.handle, C.byref(cam), C.byref(params), t.shape[0], _ptr(t, C.c_int32),

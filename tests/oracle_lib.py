@@ -265,10 +265,10 @@ class OracleScene:
 
     def render_tile_adaptive(self, cam, params, rect, spp, max_samples):
         """The reference's adaptive worker loop on one tile (main.go:837-897 + tile.go:34-66): (sums [h,w,3], counts
-        [h,w], lum [h,w,2], picks)."""
+        [h,w], stats [h,w,9] = min / max luminance, Mean, M2, Variance, picks)."""
         x0, y0, w, h = rect
         cam = np.ascontiguousarray(cam, np.float32)
-        sums = np.zeros((h, w, 3), np.float32); counts = np.zeros((h, w), np.uint32); lum = np.zeros((h, w, 2), np.float32)
+        sums = np.zeros((h, w, 3), np.float32); counts = np.zeros((h, w), np.uint32); lum = np.zeros((h, w, 9), np.float32)
         picks = self.lib.orc_render_tile_adaptive(self.h, _p(cam, C.c_float), C.byref(params), x0, y0, w, h, int(spp),
                                                   int(max_samples), _p(sums, C.c_float), _p(counts, C.c_uint32), _p(lum, C.c_float))
         if picks < 0:
@@ -286,11 +286,11 @@ class OracleScene:
 
 def pick_simulate(samples, spp, max_samples):
     """The reference's adaptive worker loop on one tile whose samples are given ([P, S, 3] float32, S > max_samples):
-    (sums [P,3], counts [P], lum [P,2], picks)."""
+    (sums [P,3], counts [P], stats [P,9], picks)."""
     lib = _load_trace()
     smp = np.ascontiguousarray(samples, np.float32)
     P, S = smp.shape[0], smp.shape[1]
-    sums = np.zeros((P, 3), np.float32); counts = np.zeros(P, np.uint32); lum = np.zeros((P, 2), np.float32)
+    sums = np.zeros((P, 3), np.float32); counts = np.zeros(P, np.uint32); lum = np.zeros((P, 9), np.float32)
     picks = lib.orc_pick_simulate(_p(smp, C.c_float), P, S, int(spp), int(max_samples), _p(sums, C.c_float),
                                   _p(counts, C.c_uint32), _p(lum, C.c_float))
     if picks < 0:

@@ -24,24 +24,32 @@ def test_pick_counts():
 
 def per_pixel_rule(samples, spp, max_samples):
     """Every pixel on its own: batches of spp samples until count >= max_samples (tile.go:39) or count > 32 and
-    contrast < 0.01 (:51); a batch ends early once count > max_samples (main.go:880)."""
+    contrast < 0.01 (:51); a batch ends early once count > max_samples (main.go:880).  Pixel.AddSample (renderer.go:25-82)
+    in numpy float32 scalars: stats = min / max luminance, Mean, M2, Variance."""
     P = samples.shape[0]
-    sums = np.zeros((P, 3), f32); counts = np.zeros(P, np.uint32); lum = np.zeros((P, 2), f32)
+    sums = np.zeros((P, 3), f32); counts = np.zeros(P, np.uint32); stats = np.zeros((P, 9), f32)
     for p in range(P):
         n = 0
-        while n < max_samples and not (n >= 4 and n > 32 and f32(lum[p, 1] - lum[p, 0]) < f32(0.01)):
+        st = stats[p]
+        while n < max_samples and not (n >= 4 and n > 32 and f32(st[1] - st[0]) < f32(0.01)):
             for _ in range(adaptive.batch_size(n, spp, max_samples)):
                 c = samples[p, n]
                 n += 1
+                fn = f32(n)
+                d = c - st[2:5]
+                st[2:5] += d / fn
+                st[5:8] += d * (c - st[2:5])
+                if n > 1:
+                    st[8] = f32(f32(st[5] + st[6]) + st[7]) / f32(f32(3.0) * f32(fn - f32(1.0)))
                 sums[p] += c
                 l = f32(f32(f32(0.2126) * c[0] + f32(0.7152) * c[1]) + f32(0.0722) * c[2])
                 if n == 1:
-                    lum[p] = l
+                    st[0] = st[1] = l
                 else:
-                    lum[p, 0] = min(lum[p, 0], l) if l < lum[p, 0] else lum[p, 0]
-                    lum[p, 1] = l if l > lum[p, 1] else lum[p, 1]
+                    if l < st[0]: st[0] = l
+                    if l > st[1]: st[1] = l
         counts[p] = n
-    return sums, counts, lum
+    return sums, counts, stats
 
 
 @pytest.mark.parametrize("spp,max_samples", [(8, 44), (32, 128), (16, 16), (5, 64), (32, 33)])
@@ -102,7 +110,7 @@ def test_oracle_loop_tracing_on_demand_equals_the_loop_on_precomputed_samples():
     assert picks == picks2
     assert np.array_equal(counts.ravel(), c2)
     assert np.array_equal(sums.reshape(-1, 3).view(np.uint32), s2.view(np.uint32))
-    assert np.array_equal(lum.reshape(-1, 2).view(np.uint32), l2.view(np.uint32))
+    assert np.array_equal(lum.reshape(-1, 9).view(np.uint32), l2.view(np.uint32))
     assert counts.min() >= 40 and counts.max() == 45 and len(np.unique(counts)) >= 2
 
 
@@ -131,7 +139,7 @@ def test_gpu_rounds_equal_the_sequential_picker(gpu_ctx, spp, max_samples):
             s2, c2, l2, _ = oracle_lib.pick_simulate(np.ascontiguousarray(smp[ys, xs]).reshape(-1, S, 3), spp, max_samples)
             assert np.array_equal(counts[ys, xs].ravel().astype(np.uint32), c2)
             assert np.array_equal(np.ascontiguousarray(accum[ys, xs]).reshape(-1, 3).view(np.uint32), s2.view(np.uint32))
-            assert np.array_equal(np.ascontiguousarray(lum[ys, xs]).reshape(-1, 2).view(np.uint32), l2.view(np.uint32))
+            assert np.array_equal(np.ascontiguousarray(lum[ys, xs]).reshape(-1, 9).view(np.uint32), l2.view(np.uint32))   # all of AddSample's state
     assert len(np.unique(counts)) >= 2 and counts.min() > 32           # background pixels stop early, noisy ones go on
     assert sum(n for n, _ in rounds) == counts.max()
     assert rounds[0][1] == W * H and rounds[-1][1] < W * H
@@ -140,7 +148,7 @@ def test_gpu_rounds_equal_the_sequential_picker(gpu_ctx, spp, max_samples):
 @pytest.mark.gpu
 def test_luminance_range_across_passes_and_lanes(monkeypatch):
     """A call cut into several passes (PTMI_CHUNK_MSAMPLES=1: 1 M samples per pass) and run on two lanes keeps the sums
-    and the luminance ranges of the same call in one pass: accumulate continues a pixel's range from the pass before."""
+    and the per-pixel statistics of the same call in one pass: accumulate continues a pixel's range from the pass before."""
     import torch
     from pathtrace_amd import Context
     sc = scenes.bunny_scene(small=True, glass=True, emissive=True)
@@ -158,10 +166,10 @@ def test_luminance_range_across_passes_and_lanes(monkeypatch):
             r = Renderer(sc, ctx=ctx)
             acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
             cnt = torch.zeros((H, W), dtype=torch.int32, device=dev)
-            lum = torch.zeros((H, W, 2), dtype=torch.float32, device=dev)
+            lum = torch.zeros((H, W, 9), dtype=torch.float32, device=dev)
             tiles = [(0, 0, W, H // 2), (0, H // 2, W // 2, H // 2), (W // 2, H // 2, W // 2, H // 2)]
-            r.render_tiles_device(acc, cnt, p, sc.camera, tiles, spp=spp - 8, lum=lum)
-            r.render_tiles_device(acc, cnt, p, sc.camera, tiles, spp=8, spp_begin=spp - 8, lum=lum)      # a later call continues too
+            r.render_tiles_device(acc, cnt, p, sc.camera, tiles, spp=spp - 8, stats=lum)
+            r.render_tiles_device(acc, cnt, p, sc.camera, tiles, spp=8, spp_begin=spp - 8, stats=lum)      # a later call continues too
             got.append((acc.cpu().numpy(), cnt.cpu().numpy(), lum.cpu().numpy()))
         finally:
             ctx.close()
@@ -178,3 +186,8 @@ def test_luminance_range_across_passes_and_lanes(monkeypatch):
         ctx.close()
     lumv = (f32(0.2126) * smp[..., 0] + f32(0.7152) * smp[..., 1]) + f32(0.0722) * smp[..., 2]
     assert np.array_equal(lumv.min(-1), l0[60:68, 100:132, 0]) and np.array_equal(lumv.max(-1), l0[60:68, 100:132, 1])
+    # ... and mean / variance are Welford's: close to the two-pass values (float32 running sums)
+    mean = smp.astype(np.float64).mean(2)
+    assert np.allclose(l0[60:68, 100:132, 2:5], mean, rtol=1e-4, atol=1e-5)
+    var = smp.astype(np.float64).var(2, ddof=1).sum(-1) / 3.0
+    assert np.allclose(l0[60:68, 100:132, 8], var, rtol=1e-3, atol=1e-6)
