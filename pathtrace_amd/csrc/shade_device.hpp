@@ -203,13 +203,14 @@ __device__ __forceinline__ void get_acceleration(const RayState &s, float rs, fl
     // the bit patterns of such floats order like their values; NaN and infinity lie above MID_HI)
     const float lo = fmaxf(rs * rs, MID_LO);
     const uint32_t span = lo < MID_HI ? __float_as_uint(MID_HI) - __float_as_uint(lo) - 1u : 0u;   // (uniform: the compiler hoists it out of the march)
-    float r, inv_r_cubed, r_cubed;
-    if (PTMI_MID_MATH && __float_as_uint(r_sq) - __float_as_uint(lo) - 1u < span) {
-        r = sqrt_mid(r_sq);
-        r_cubed = r_sq * r;
-        inv_r_cubed = rcp_mid(r_cubed);
-    } else {
-        if (r_sq <= rs * rs) { at = ax = ay = az = 0.0f; return; }
+    // every lane runs the short forms (for an argument outside their range the value is simply not used); the lanes
+    // outside -- inside the horizon, or at the ends of the exponent range -- are the rare ones and take the branch
+    float r = sqrt_mid(r_sq);
+    float r_cubed = r_sq * r;
+    float inv_r_cubed = rcp_mid(r_cubed);
+    bool inside = false;
+    if (!(PTMI_MID_MATH && __float_as_uint(r_sq) - __float_as_uint(lo) - 1u < span)) {
+        inside = r_sq <= rs * rs;
         r = sqrtf(r_sq);
         r_cubed = r_sq * r;
         inv_r_cubed = 1.0f / r_cubed;
@@ -224,6 +225,7 @@ __device__ __forceinline__ void get_acceleration(const RayState &s, float rs, fl
     ax = px * rs_inv_factor + rs * two * vx;
     ay = py * rs_inv_factor + rs * two * vy;
     az = pz * rs_inv_factor + rs * two * vz;
+    if (inside) { at = ax = ay = az = 0.0f; }                          // BlackHole.go:82-84
 }
 struct Rk4D { float at, ax, ay, az, vt, vx, vy, vz; };
 // BlackHole.go:118-127
