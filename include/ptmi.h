@@ -279,6 +279,16 @@ int ptmi_render_tiles_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams 
 int ptmi_render_tiles_stats_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t ntiles,
                                 const int32_t *tiles_xywh, uint32_t spp_begin, uint32_t spp_count, float *accum_rgb,
                                 uint32_t *counts, float *pixel_stats, void *stream);
+/* The whole adaptive frame in one call: what the reference's worker loop (main.go:837-897) around
+ * Tile.GetNoisiestPixel(maxSamplesPerPixel) (tile.go:34-66) leaves in the Pixels when every tile reports "completed
+ * rendering", with samples_per_pixel = samplesPerPixel and max_samples = maxSamplesPerPixel.  Two passes as described
+ * above: every pixel up to the first SampleCount above 32, then the pixels whose Contrast is not under 0.01 up to the
+ * count at which the picker drops them (max_samples, or the first count above it when it is not a multiple of the batch:
+ * main.go:880).  accum_rgb / counts / pixel_stats are full-frame device buffers as for ptmi_render_tiles_stats_dev,
+ * ZEROED by the caller (a fresh frame).  The order in which the picker would have visited the pixels is not reproduced
+ * (it does not change the result); tests/test_adaptive.py holds the frame against the sequential loop bit for bit. */
+int ptmi_render_adaptive_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t samples_per_pixel,
+                             uint32_t max_samples, float *accum_rgb, uint32_t *counts, float *pixel_stats, void *stream);
 /* Several frames of one scene in ONE call -- the orbit of the reference's frame loop (main.go:903-937: when all tile
  * workers are done save orbit/frame<j>.png, theta += 1 degree, `scene.Camera.SphericalAround(Vec3{}, 1500, theta, phi)`
  * (camera.go:17), start the workers again), nframes cameras at a time: frame f is rendered through

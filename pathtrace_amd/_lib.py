@@ -105,6 +105,8 @@ SIGNATURES = {
                                        C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ptmi_render_tiles_stats_dev": (C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), C.c_uint32, C.POINTER(C.c_int32),
                                              C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ptmi_render_adaptive_dev": (C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ptmi_render_frames_dev": (C.c_int, [_P, C.POINTER(PtCamera), C.c_uint32, C.POINTER(PtParams), C.c_uint32, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "ptmi_render_samples": (C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), C.c_int32, C.c_int32, C.c_int32,

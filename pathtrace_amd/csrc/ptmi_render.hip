@@ -1864,6 +1864,15 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float *__restrict
     }
 }
 
+// Tile.GetNoisiestPixel's convergence test on Pixel.Contrast = MaxLuminance - MinLuminance (tile.go:51, renderer.go:81):
+// 1 = the pixel goes on, 0 = it is done (a NaN contrast is never < 0.01: the pixel goes on, as in the reference).
+__global__ __launch_bounds__(256) void adaptive_mask_kernel(const float *__restrict__ stats, uint32_t npix, uint8_t *mask) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= npix) return;
+    const float *st = stats + (size_t)PTMI_PIXEL_STATS * i;
+    mask[i] = (st[1] - st[0] < (float)0.01) ? 0 : 1;
+}
+
 }  // namespace
 
 // ============================================================================================ host side
@@ -2584,6 +2593,51 @@ extern "C" int ptmi_render_tiles_stats_dev(ptmi_ctx *ctx, const PtCamera *camera
                                            uint32_t *counts, float *pixel_stats, void *stream) {
     if (ctx && !pixel_stats) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_tiles_stats_dev: pixel_stats is null");
     return render_tiles(ctx, camera, params, ntiles, tiles_xywh, spp_begin, spp_count, accum_rgb, counts, pixel_stats, stream);
+}
+
+// The reference's adaptive worker loop (main.go:837-897 around Tile.GetNoisiestPixel, tile.go:34-66) as TWO passes over
+// the frame -- see ptmi.h.
+extern "C" int ptmi_render_adaptive_dev(ptmi_ctx *ctx, const PtCamera *camera, const PtParams *params, uint32_t samples_per_pixel,
+                                        uint32_t max_samples, float *accum_rgb, uint32_t *counts, float *pixel_stats, void *stream) {
+    if (!ctx) return set_err(nullptr, PTMI_ERR_INVALID, "ptmi_render_adaptive_dev: ctx is null");
+    if (!params || !accum_rgb || !counts || !pixel_stats) return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_adaptive_dev: null argument");
+    if (samples_per_pixel < 1 || max_samples < 1 || max_samples > (1u << 24) || params->width <= 0 || params->height <= 0)
+        return set_err(ctx, PTMI_ERR_INVALID, "ptmi_render_adaptive_dev: need samples_per_pixel >= 1, 1 <= max_samples <= 2^24, a non-empty image");
+    // SampleCount after each pick of a pixel that never converges: a pick adds samples_per_pixel samples but stops once
+    // SampleCount > max_samples (main.go:861-883).  `tested` = the first of those counts above 32 that is not the last:
+    // the count at which the contrast test (tile.go:51) first decides anything; `cap` = where such a pixel stops.
+    uint32_t cap = 0, tested = 0;
+    while (cap < max_samples) {
+        if (cap > 32 && !tested) tested = cap;
+        cap += std::min(samples_per_pixel, max_samples + 1 - cap);
+    }
+    const int32_t whole[4] = {0, 0, params->width, params->height};
+    int rc = render_tiles(ctx, camera, params, 1, whole, 0, tested ? tested : cap, accum_rgb, counts, pixel_stats, stream);
+    if (rc || !tested) return rc;
+    RenderState *rs = ctx->render;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t npix = (size_t)params->width * (size_t)params->height;
+    if (!rs || !rs->d_out || rs->out_bytes < npix) return set_err(ctx, PTMI_ERR_HIP, "ptmi_render_adaptive_dev: no scratch buffer after the first pass");
+    // who goes on: the mask is computed on the device (into the idle per-sample output buffer) and read back; the runs of
+    // pixels that go on become 1-row tiles.  A pixel's contrast only grows with more samples, so one look is enough.
+    uint8_t *d_mask = (uint8_t *)rs->d_out;
+    hipLaunchKernelGGL(adaptive_mask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, pixel_stats, (uint32_t)npix, d_mask);
+    PTMI_HIP(ctx, hipGetLastError());
+    std::vector<uint8_t> mask(npix);
+    PTMI_HIP(ctx, hipMemcpyAsync(mask.data(), d_mask, npix, hipMemcpyDeviceToHost, s));
+    PTMI_HIP(ctx, hipStreamSynchronize(s));
+    std::vector<int32_t> runs;
+    for (int32_t y = 0; y < params->height; ++y) {
+        const uint8_t *row = mask.data() + (size_t)y * params->width;
+        for (int32_t x = 0; x < params->width;) {
+            if (!row[x]) { ++x; continue; }
+            const int32_t x0 = x;
+            while (x < params->width && row[x]) ++x;
+            runs.insert(runs.end(), {x0, y, x - x0, 1});
+        }
+    }
+    if (runs.empty()) return PTMI_OK;
+    return render_tiles(ctx, camera, params, (uint32_t)(runs.size() / 4), runs.data(), tested, cap - tested, accum_rgb, counts, pixel_stats, stream);
 }
 
 extern "C" int ptmi_render_frames_dev(ptmi_ctx *ctx, const PtCamera *cameras, uint32_t nframes, const PtParams *params, uint32_t spp_begin,

@@ -218,6 +218,17 @@ class Renderer:
         check(self._lib.ptmi_render_tiles_dev(self.ctx.handle, C.byref(cam), C.byref(params), t.shape[0], _ptr(t, C.c_int32),
                                               spp_begin, spp, accum.data_ptr(), counts.data_ptr(), s), self.ctx.handle)
 
+    def render_adaptive_device(self, accum, counts, stats, params: PtParams, camera, samples_per_pixel=32, max_samples=1024, stream=None):
+        """The frame the reference's adaptive worker loop ends with (main.go:837-897, tile.go:34-66), in one call
+        (ptmi_render_adaptive_dev): zeroed full-frame torch CUDA tensors accum [H,W,3], counts [H,W], stats [H,W,9]."""
+        cam = camera if isinstance(camera, PtCamera) else make_camera(camera)
+        assert tuple(accum.shape) == (params.height, params.width, 3) and accum.is_contiguous()
+        assert tuple(counts.shape) == (params.height, params.width) and counts.is_contiguous()
+        assert tuple(stats.shape) == (params.height, params.width, self.PIXEL_STATS) and stats.is_contiguous() and stats.element_size() == 4
+        s = C.c_void_p(stream) if stream else None
+        check(self._lib.ptmi_render_adaptive_dev(self.ctx.handle, C.byref(cam), C.byref(params), int(samples_per_pixel), int(max_samples),
+                                                 accum.data_ptr(), counts.data_ptr(), stats.data_ptr(), s), self.ctx.handle)
+
     def render_frames_device(self, accum, counts, params: PtParams, cameras, spp=32, spp_begin=0, stream=None):
         """Several frames of the scene in one call (the reference's orbit, main.go:903-937, a batch of cameras at a time):
         frame f through cameras[f], added into accum[f] / counts[f] of contiguous torch CUDA tensors [F,H,W,3] / [F,H,W].

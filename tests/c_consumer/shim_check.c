@@ -139,6 +139,8 @@ static void gpu_checks(void) {
         }
         /* ptmi_render_tiles_stats_dev takes device buffers (the Python tests drive it); its argument checks from here */
         CHECK(ptmi_render_tiles_stats_dev(ctx, &cam, &prm, 0, NULL, 0, 1, accum, counts, NULL, NULL) == PTMI_ERR_INVALID);
+        CHECK(ptmi_render_adaptive_dev(ctx, &cam, &prm, 0, 64, accum, counts, accum, NULL) == PTMI_ERR_INVALID);      /* batch of 0 */
+        CHECK(ptmi_render_adaptive_dev(ctx, &cam, &prm, 32, 64, accum, counts, NULL, NULL) == PTMI_ERR_INVALID);
     }
     ptmi_destroy(ctx);
 }

@@ -28,6 +28,13 @@ for merge in (True, False):
     n = int(cnt.sum().item())
     print(f"{'two calls' if merge else 'one call per batch'}: {n} samples ({n / cnt.numel():.1f} per pixel, "
           f"{int(cnt.min().item())}..{int(cnt.max().item())}) in {len(calls)} calls, {dt * 1e3:.1f} ms = {n / dt / 1e6:.1f} Msamples/s")
+for rep in range(2):
+    acc.zero_(); cnt.zero_(); lum.zero_()
+    torch.cuda.synchronize(); t0 = time.time()
+    r.render_adaptive_device(acc, cnt, lum, p, sc.camera, samples_per_pixel=a.spp, max_samples=a.max_spp)
+    torch.cuda.synchronize(); dt = time.time() - t0
+n = int(cnt.sum().item())
+print(f"ptmi_render_adaptive_dev: {n} samples in {dt * 1e3:.1f} ms = {n / dt / 1e6:.1f} Msamples/s")
 dev = acc.device
 acc = torch.zeros_like(acc); cnt = torch.zeros_like(cnt)
 for rep in range(2):
