@@ -127,10 +127,10 @@ def test_gpu_rounds_equal_the_sequential_picker(gpu_ctx, spp, max_samples):
     accum, counts, lum, rounds = adaptive.render_adaptive(r, p, sc.camera, samples_per_pixel=spp, max_samples=max_samples, merge=False)
     merged = adaptive.render_adaptive(r, p, sc.camera, samples_per_pixel=spp, max_samples=max_samples)        # two calls
     assert len(merged[3]) == 2 and len(rounds) == len(adaptive.pick_counts(spp, max_samples))
-    for a, b in zip((accum, counts, lum), merged[:3]):
-        assert (a.view(dtype=__import__("torch").int32) == b.view(dtype=__import__("torch").int32)).all()
-    # ... and the library's own two passes (ptmi_render_adaptive_dev)
     import torch
+    for a, b in zip((accum, counts, lum), merged[:3]):
+        assert (a.view(dtype=torch.int32) == b.view(dtype=torch.int32)).all()
+    # ... and the library's own two passes (ptmi_render_adaptive_dev)
     nat = [torch.zeros_like(t) for t in (accum, counts, lum)]
     r.render_adaptive_device(nat[0], nat[1], nat[2], p, sc.camera, samples_per_pixel=spp, max_samples=max_samples)
     for a, b in zip((accum, counts, lum), nat):
