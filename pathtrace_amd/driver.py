@@ -249,13 +249,18 @@ def main():
     if a.orbit_radius > 0 or a.scene == "c5":
         orbit = (a.orbit_radius or 1500.0, 90.0 * DEG, 83.0 * DEG)      # main.go:625-631
     if a.max_spp > a.spp:
-        from . import adaptive
+        import torch
         from .render import Framebuffer
+        dev = torch.device("cuda", 0)
+        acc = torch.zeros((p.height, p.width, 3), dtype=torch.float32, device=dev)
+        cnt = torch.zeros((p.height, p.width), dtype=torch.int32, device=dev)
+        stats = torch.zeros((p.height, p.width, r.PIXEL_STATS), dtype=torch.float32, device=dev)
         t0 = time.time()
-        acc, cnt, _, rounds = adaptive.render_adaptive(r, p, sc.camera, samples_per_pixel=a.spp, max_samples=a.max_spp, log=print)
-        c = cnt.cpu().numpy().astype(np.uint32)
+        r.render_adaptive_device(acc, cnt, stats, p, sc.camera, samples_per_pixel=a.spp, max_samples=a.max_spp)   # ptmi_render_adaptive_dev
+        torch.cuda.synchronize()
         dt = time.time() - t0
-        print(f">> {int(c.sum())} samples in {len(rounds)} calls, {humanize(c.sum() / max(dt, 1e-9))} samples/s; "
+        c = cnt.cpu().numpy().astype(np.uint32)
+        print(f">> {int(c.sum())} samples, {humanize(c.sum() / max(dt, 1e-9))} samples/s; "
               f"{float(c.mean()):.1f} per pixel (min {int(c.min())}, max {int(c.max())})")
         os.makedirs(a.out, exist_ok=True)
         write_png(os.path.join(a.out, "adaptive.png"), r.to_rgba(Framebuffer(acc.cpu().numpy(), c)))
